@@ -1,0 +1,166 @@
+// extern "C" surface of libfp8mi.so: argument validation, kernel selection,
+// error reporting.  See include/fp8mi.h for the contract of every entry point
+// and the reference interface each one replaces.
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "fp8mi_common.h"
+
+int fp8mi_launch_dequant(const uint8_t *in, void *out, const float *scale, int64_t count, int out_dtype, hipStream_t s);
+int fp8mi_launch_encode(const void *in, int in_dtype, uint8_t *out, const float *prescale, int64_t count, int mode,
+                        hipStream_t s);
+int fp8mi_launch_amax(const void *in, int in_dtype, float *out, int64_t count, hipStream_t s);
+int fp8mi_launch_quantize(const void *in, int in_dtype, uint8_t *out, float *scales, int64_t count, int mode,
+                          hipStream_t s);
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_result(int rc, const char *what)
+{
+    if (rc > 0) return fail(rc, "%s: %s", what, hipGetErrorString((hipError_t)rc));
+    if (rc < 0) return fail(rc, "%s: unsupported problem for the selected kernel", what);
+    return 0;
+}
+
+bool dtype_ok(int d) { return d == FP8MI_F32 || d == FP8MI_F16 || d == FP8MI_BF16; }
+
+}  // namespace
+
+extern "C" {
+
+int fp8mi_version(void) { return FP8MI_VERSION; }
+
+const char *fp8mi_last_error(void) { return g_err; }
+
+int fp8mi_device_info(int device, fp8mi_device_info_t *out)
+{
+    if (!out) return fail(FP8MI_E_NULL, "fp8mi_device_info: out is NULL");
+    hipDeviceProp_t pr;
+    hipError_t e = hipGetDeviceProperties(&pr, device);
+    if (e != hipSuccess) return fail((int)e, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    memset(out, 0, sizeof(*out));
+    out->compute_units = pr.multiProcessorCount;
+    out->clock_khz = pr.clockRate;
+    out->memory_clock_khz = pr.memoryClockRate;
+    out->memory_bus_bits = pr.memoryBusWidth;
+    out->l2_bytes = pr.l2CacheSize;
+    out->lds_bytes_per_cu = (int)pr.maxSharedMemoryPerMultiProcessor;
+    out->wavefront_size = pr.warpSize;
+    out->total_memory = (int64_t)pr.totalGlobalMem;
+    strncpy(out->arch, pr.gcnArchName, sizeof(out->arch) - 1);
+    strncpy(out->name, pr.name, sizeof(out->name) - 1);
+    return 0;
+}
+
+int fp8mi_scaled_mm_ex(const uint8_t *A, const uint8_t *B_nk, void *C, const float *scale_a, const float *scale_b,
+                       const void *bias, const float *scale_result, int64_t M, int64_t N, int64_t K, int64_t lda,
+                       int64_t ldb, int64_t ldc, int scale_a_mode, int scale_b_mode, int out_dtype, int bias_dtype,
+                       int nan_mode, int kernel, void *stream)
+{
+    if (M < 0 || N < 0 || K < 0) return fail(FP8MI_E_SHAPE, "fp8mi_scaled_mm: negative dimension (M=%lld N=%lld K=%lld)",
+                                              (long long)M, (long long)N, (long long)K);
+    if (M == 0 || N == 0) return 0;
+    if (!C || !scale_a || !scale_b) return fail(FP8MI_E_NULL, "fp8mi_scaled_mm: C / scale_a / scale_b must not be NULL");
+    if (K > 0 && (!A || !B_nk)) return fail(FP8MI_E_NULL, "fp8mi_scaled_mm: A / B must not be NULL when K > 0");
+    if (lda < K || ldb < K || ldc < N)
+        return fail(FP8MI_E_SHAPE, "fp8mi_scaled_mm: leading dimension too small (lda=%lld ldb=%lld ldc=%lld)",
+                    (long long)lda, (long long)ldb, (long long)ldc);
+    if (!dtype_ok(out_dtype) || (bias && !dtype_ok(bias_dtype)))
+        return fail(FP8MI_E_ENUM, "fp8mi_scaled_mm: unknown out_dtype / bias_dtype");
+    if ((scale_a_mode | 1) != 1 || (scale_b_mode | 1) != 1 || (nan_mode | 1) != 1)
+        return fail(FP8MI_E_ENUM, "fp8mi_scaled_mm: unknown scale mode / nan mode");
+
+    MMParams p;
+    p.A = A; p.B = B_nk; p.C = C;
+    p.scale_a = scale_a; p.scale_b = scale_b; p.bias = bias; p.scale_result = scale_result;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.sa_row = scale_a_mode; p.sb_row = scale_b_mode;
+    p.out_dtype = out_dtype; p.bias_dtype = bias_dtype;
+    p.nan_zero = nan_mode == FP8MI_NAN_ZERO;
+    hipStream_t s = (hipStream_t)stream;
+
+    switch (kernel) {
+    case FP8MI_KERNEL_AUTO:
+        if (fp8mi_gemv_supported(p)) return hip_result(fp8mi_launch_gemv(p, s), "gemv");
+        if (fp8mi_skinny_supported(p)) return hip_result(fp8mi_launch_skinny(p, s), "skinny");
+        if (K > 0 && fp8mi_gemm_supported(p)) return hip_result(fp8mi_launch_gemm(p, FP8MI_KERNEL_AUTO, s), "gemm");
+        return hip_result(fp8mi_launch_generic(p, s), "generic");
+    case FP8MI_KERNEL_GEMV:
+        if (!fp8mi_gemv_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "gemv kernel needs M == 1, K %% 16 == 0, 16-byte aligned rows");
+        return hip_result(fp8mi_launch_gemv(p, s), "gemv");
+    case FP8MI_KERNEL_SKINNY:
+        if (!fp8mi_skinny_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "skinny kernel needs 1 <= M <= 16, K %% 16 == 0, 16-byte aligned rows");
+        return hip_result(fp8mi_launch_skinny(p, s), "skinny");
+    case FP8MI_KERNEL_GEMM_128:
+    case FP8MI_KERNEL_GEMM_128x64:
+    case FP8MI_KERNEL_GEMM_256:
+        if (!fp8mi_gemm_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "MFMA gemm kernel needs K %% 16 == 0 and 16-byte aligned rows");
+        return hip_result(fp8mi_launch_gemm(p, kernel, s), "gemm");
+    case FP8MI_KERNEL_GENERIC:
+        return hip_result(fp8mi_launch_generic(p, s), "generic");
+    default:
+        return fail(FP8MI_E_ENUM, "fp8mi_scaled_mm_ex: unknown kernel id %d", kernel);
+    }
+}
+
+int fp8mi_scaled_mm(const uint8_t *A, const uint8_t *B_nk, void *C, const float *scale_a, const float *scale_b,
+                    const void *bias, const float *scale_result, int64_t M, int64_t N, int64_t K, int64_t lda,
+                    int64_t ldb, int64_t ldc, int scale_a_mode, int scale_b_mode, int out_dtype, int bias_dtype,
+                    int nan_mode, void *stream)
+{
+    return fp8mi_scaled_mm_ex(A, B_nk, C, scale_a, scale_b, bias, scale_result, M, N, K, lda, ldb, ldc, scale_a_mode,
+                              scale_b_mode, out_dtype, bias_dtype, nan_mode, FP8MI_KERNEL_AUTO, stream);
+}
+
+int fp8mi_dequant(const uint8_t *in, void *out, const float *scale, int64_t count, int out_dtype, void *stream)
+{
+    if (count < 0) return fail(FP8MI_E_SHAPE, "fp8mi_dequant: negative count");
+    if (count == 0) return 0;
+    if (!in || !out) return fail(FP8MI_E_NULL, "fp8mi_dequant: in / out must not be NULL");
+    if (!dtype_ok(out_dtype)) return fail(FP8MI_E_ENUM, "fp8mi_dequant: unknown out_dtype %d", out_dtype);
+    return hip_result(fp8mi_launch_dequant(in, out, scale, count, out_dtype, (hipStream_t)stream), "dequant");
+}
+
+int fp8mi_encode(const void *in, int in_dtype, uint8_t *out, const float *prescale, int64_t count, int encode_mode,
+                 void *stream)
+{
+    if (count < 0) return fail(FP8MI_E_SHAPE, "fp8mi_encode: negative count");
+    if (count == 0) return 0;
+    if (!in || !out) return fail(FP8MI_E_NULL, "fp8mi_encode: in / out must not be NULL");
+    if (!dtype_ok(in_dtype)) return fail(FP8MI_E_ENUM, "fp8mi_encode: unknown in_dtype %d", in_dtype);
+    if ((encode_mode | 1) != 1) return fail(FP8MI_E_ENUM, "fp8mi_encode: unknown encode_mode %d", encode_mode);
+    return hip_result(fp8mi_launch_encode(in, in_dtype, out, prescale, count, encode_mode, (hipStream_t)stream), "encode");
+}
+
+int fp8mi_amax(const void *in, int in_dtype, float *out, int64_t count, void *stream)
+{
+    if (count < 0) return fail(FP8MI_E_SHAPE, "fp8mi_amax: negative count");
+    if (!out || (count > 0 && !in)) return fail(FP8MI_E_NULL, "fp8mi_amax: in / out must not be NULL");
+    if (!dtype_ok(in_dtype)) return fail(FP8MI_E_ENUM, "fp8mi_amax: unknown in_dtype %d", in_dtype);
+    return hip_result(fp8mi_launch_amax(in, in_dtype, out, count, (hipStream_t)stream), "amax");
+}
+
+int fp8mi_quantize(const void *in, int in_dtype, uint8_t *out, float *scales, int64_t count, int encode_mode,
+                   void *stream)
+{
+    if (count < 0) return fail(FP8MI_E_SHAPE, "fp8mi_quantize: negative count");
+    if (!scales || (count > 0 && (!in || !out))) return fail(FP8MI_E_NULL, "fp8mi_quantize: NULL pointer");
+    if (!dtype_ok(in_dtype)) return fail(FP8MI_E_ENUM, "fp8mi_quantize: unknown in_dtype %d", in_dtype);
+    if ((encode_mode | 1) != 1) return fail(FP8MI_E_ENUM, "fp8mi_quantize: unknown encode_mode %d", encode_mode);
+    return hip_result(fp8mi_launch_quantize(in, in_dtype, out, scales, count, encode_mode, (hipStream_t)stream), "quantize");
+}
+
+}  // extern "C"

@@ -1,0 +1,432 @@
+// Elementwise FP8 e4m3fn casts for gfx950: dequant (fp8 -> f16/f32/bf16),
+// encode (f32/f16/bf16 -> fp8), amax, and the device-side scale derivation of
+// the amax-scaled quantiser.  All are HBM-bound streaming kernels: 16 bytes of
+// fp8 per lane per step, dwordx4 loads and stores, grid-stride over at most
+// 2048 workgroups so the launch fills the 256 CUs without a long block queue.
+//
+// Reference kernels replaced: fp8_to_half_kernel (fp8_matmul.metal:215-223),
+// float_to_fp8_kernel (:228-236); reference math restated: decode :19-40,
+// encode :44-92.
+
+#include "fp8mi_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxGrid = 2048;
+
+// ---------------------------------------------------------------------------
+// decode: four packed fp8 bytes -> four halves (two packed dwords), exact.
+// Bit trick: fp8 [s eeee mmm] placed at half bits [15 | 13:7] is the half
+// 2^(e-15)(1+m/8) (or the half-subnormal m/8 * 2^-14 for e == 0); multiplying
+// by 2^8 rebiases it to the e4m3 value 2^(e-7)(1+m/8) (m/8 * 2^-6).  NaN
+// patterns become +0.0 first (fp8_matmul.metal:21).
+// ---------------------------------------------------------------------------
+FP8MI_DEVICE uint32_t fp8x2_to_half2_bits(uint32_t x /* bytes at [15:8] and [31:24] */)
+{
+    uint32_t t = x & 0x7F007F00u;
+    uint32_t h = (x & 0x80008000u) | (t >> 1);
+    uint32_t m = (t + 0x01000100u) & 0x80008000u;  // bit15 of a half set iff its byte is NaN
+    m = m | (m - (m >> 15));                       // 0xFFFF per NaN half
+    return h & ~m;
+}
+
+FP8MI_DEVICE void decode4_half(uint32_t w, f16x2 &lo, f16x2 &hi)
+{
+    uint32_t a = __builtin_amdgcn_perm(0u, w, 0x010c000cu);  // (b0 << 8) | (b1 << 24)
+    uint32_t b = __builtin_amdgcn_perm(0u, w, 0x030c020cu);  // (b2 << 8) | (b3 << 24)
+    const f16x2 k256 = {(_Float16)256.0f, (_Float16)256.0f};
+    lo = __builtin_bit_cast(f16x2, fp8x2_to_half2_bits(a)) * k256;
+    hi = __builtin_bit_cast(f16x2, fp8x2_to_half2_bits(b)) * k256;
+}
+
+template <int OUT>
+struct OutVec;  // 16 output elements
+
+template <>
+struct OutVec<FP8MI_F16> {
+    static FP8MI_DEVICE void store(void *out, int64_t i16, const f16x2 (&h)[8])
+    {
+        u32x4 *o = (u32x4 *)out + i16 * 2;
+        u32x4 v0, v1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v0[j] = __builtin_bit_cast(uint32_t, h[j]);
+            v1[j] = __builtin_bit_cast(uint32_t, h[4 + j]);
+        }
+        o[0] = v0;
+        o[1] = v1;
+    }
+    static FP8MI_DEVICE void store1(void *out, int64_t i, _Float16 v) { ((_Float16 *)out)[i] = v; }
+};
+
+template <>
+struct OutVec<FP8MI_F32> {
+    static FP8MI_DEVICE void store(void *out, int64_t i16, const f16x2 (&h)[8])
+    {
+        f32x4 *o = (f32x4 *)out + i16 * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = {(float)h[2 * j][0], (float)h[2 * j][1], (float)h[2 * j + 1][0], (float)h[2 * j + 1][1]};
+            o[j] = v;
+        }
+    }
+    static FP8MI_DEVICE void store1(void *out, int64_t i, _Float16 v) { ((float *)out)[i] = (float)v; }
+};
+
+template <>
+struct OutVec<FP8MI_BF16> {
+    static FP8MI_DEVICE uint32_t pack(f16x2 h)
+    {
+        __bf16 a = (__bf16)(float)h[0], b = (__bf16)(float)h[1];
+        return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+    }
+    static FP8MI_DEVICE void store(void *out, int64_t i16, const f16x2 (&h)[8])
+    {
+        u32x4 *o = (u32x4 *)out + i16 * 2;
+        u32x4 v0, v1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v0[j] = pack(h[j]);
+            v1[j] = pack(h[4 + j]);
+        }
+        o[0] = v0;
+        o[1] = v1;
+    }
+    static FP8MI_DEVICE void store1(void *out, int64_t i, _Float16 v) { ((__bf16 *)out)[i] = (__bf16)(float)v; }
+};
+
+// in/out 16-byte aligned; n16 = count / 16 full vectors, then a scalar tail.
+template <int OUT>
+__global__ __launch_bounds__(kBlock) void dequant_kernel(const uint8_t *__restrict__ in, void *__restrict__ out,
+                                                          const float *__restrict__ scale, int64_t count)
+{
+    const bool has_scale = scale != nullptr;
+    _Float16 s = has_scale ? (_Float16)scale[0] : (_Float16)1.0f;  // scale.to(float16)
+    const f16x2 s2 = {s, s};
+    const int64_t n16 = count >> 4;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const u32x4 *in4 = (const u32x4 *)in;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += stride) {
+        u32x4 w = __builtin_nontemporal_load(in4 + i);
+        f16x2 h[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) decode4_half(w[j], h[2 * j], h[2 * j + 1]);
+        if (has_scale) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = h[j] * s2;
+        }
+        OutVec<OUT>::store(out, i, h);
+    }
+    // tail (< 16 elements): first block, one element per lane
+    if (blockIdx.x == 0) {
+        int64_t i = (n16 << 4) + threadIdx.x;
+        if (i < count) {
+            _Float16 v = (_Float16)decode_ref(in[i]);
+            if (has_scale) v = v * s;
+            OutVec<OUT>::store1(out, i, v);
+        }
+    }
+}
+
+// unaligned fallback: one element per lane per step
+template <int OUT>
+__global__ __launch_bounds__(kBlock) void dequant_scalar_kernel(const uint8_t *__restrict__ in, void *__restrict__ out,
+                                                                 const float *__restrict__ scale, int64_t count)
+{
+    const bool has_scale = scale != nullptr;
+    _Float16 s = has_scale ? (_Float16)scale[0] : (_Float16)1.0f;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) {
+        _Float16 v = (_Float16)decode_ref(in[i]);
+        if (has_scale) v = v * s;
+        OutVec<OUT>::store1(out, i, v);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// encode: float32 bits -> fp8 byte, integer-only.
+// ---------------------------------------------------------------------------
+
+// reference semantics (fp8_matmul.metal:44-92, exact-arithmetic behaviour of
+// its Python twin test_fp8_correctness.py:53-106)
+FP8MI_DEVICE uint32_t encode_ref_bits(uint32_t bits)
+{
+    uint32_t a = bits & 0x7FFFFFFFu;
+    uint32_t sign = (a != 0u) ? ((bits >> 24) & 0x80u) : 0u;  // `val < 0`: -0.0 has no sign (:46)
+    uint32_t e = a >> 23, man = a & 0x7FFFFFu;
+    // normal range: top three mantissa bits, RNE on the low 20, clamp (no carry, :79-81)
+    uint32_t qn = (man + 0x7FFFFu + ((man >> 20) & 1u)) >> 20;
+    qn = min(qn, 7u);
+    uint32_t eb = e - 120u;
+    qn = (eb == 15u && qn == 7u) ? 6u : qn;  // never the NaN pattern (:87-89)
+    uint32_t normal = (eb << 3) | qn;
+    // subnormal range [2^-9, 2^-6): mant = RNE(val * 512), clamp to 7 (:64-70)
+    uint32_t s = 141u - e;  // 21..23 in this range
+    s = min(max(s, 1u), 31u);
+    uint32_t full = man | 0x800000u;
+    uint32_t qs = (full + ((1u << (s - 1u)) - 1u) + ((full >> s) & 1u)) >> s;
+    qs = min(qs, 7u);
+    uint32_t r = (a < 0x3C800000u) ? qs : normal;  // < 2^-6
+    r = (a < 0x3B000000u) ? 0u : r;                 // < 2^-9 flushes, sign kept (:58-60)
+    r = (a >= 0x43E00000u) ? 0x7Eu : r;             // >= 448 saturates, also inf (:53-55)
+    r |= sign;
+    return (a > 0x7F800000u) ? 0x7Fu : r;           // NaN in: outside the reference's domain
+}
+
+// OCP e4m3fn round-to-nearest-even with overflow to NaN: what torch-CPU
+// `.to(torch.float8_e4m3fn)` produces (non-default mode).
+FP8MI_DEVICE uint32_t encode_rne_bits(uint32_t bits)
+{
+    uint32_t a = bits & 0x7FFFFFFFu;
+    uint32_t sign = (bits >> 24) & 0x80u;
+    uint32_t e = a >> 23, man = a & 0x7FFFFFu;
+    uint32_t v = ((e - 120u) << 23) | man;
+    uint32_t n = (v + 0x7FFFFu + ((v >> 20) & 1u)) >> 20;  // carry may bump the exponent
+    uint32_t s = min(max(141u - e, 1u), 31u);
+    uint32_t full = man | 0x800000u;
+    uint32_t qs = (full + ((1u << (s - 1u)) - 1u) + ((full >> s) & 1u)) >> s;
+    qs = (e < 110u) ? 0u : qs;  // below 2^-17: far under half the smallest subnormal
+    uint32_t r = (e < 121u) ? qs : n;
+    r = (r > 0x7Eu) ? 0x7Fu : r;
+    r = (a > 0x7F800000u) ? 0x7Fu : r;
+    return r | sign;
+}
+
+template <int MODE>
+FP8MI_DEVICE uint32_t encode_bits(float v)
+{
+    uint32_t b = __float_as_uint(v);
+    return MODE == FP8MI_ENC_REFERENCE ? encode_ref_bits(b) : encode_rne_bits(b);
+}
+
+template <int IN>
+struct InVec;  // loads 16 elements as float
+
+template <>
+struct InVec<FP8MI_F32> {
+    static FP8MI_DEVICE void load(const void *in, int64_t i16, float (&f)[16])
+    {
+        const f32x4 *p = (const f32x4 *)in + i16 * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = __builtin_nontemporal_load(p + j);
+            f[4 * j] = v[0]; f[4 * j + 1] = v[1]; f[4 * j + 2] = v[2]; f[4 * j + 3] = v[3];
+        }
+    }
+    static FP8MI_DEVICE float load1(const void *in, int64_t i) { return ((const float *)in)[i]; }
+};
+
+template <>
+struct InVec<FP8MI_F16> {
+    static FP8MI_DEVICE void load(const void *in, int64_t i16, float (&f)[16])
+    {
+        const u32x4 *p = (const u32x4 *)in + i16 * 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            u32x4 v = __builtin_nontemporal_load(p + j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f16x2 h = __builtin_bit_cast(f16x2, v[q]);
+                f[8 * j + 2 * q] = (float)h[0];
+                f[8 * j + 2 * q + 1] = (float)h[1];
+            }
+        }
+    }
+    static FP8MI_DEVICE float load1(const void *in, int64_t i) { return (float)((const _Float16 *)in)[i]; }
+};
+
+template <>
+struct InVec<FP8MI_BF16> {
+    static FP8MI_DEVICE void load(const void *in, int64_t i16, float (&f)[16])
+    {
+        const u32x4 *p = (const u32x4 *)in + i16 * 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            u32x4 v = __builtin_nontemporal_load(p + j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f[8 * j + 2 * q] = __uint_as_float(v[q] << 16);
+                f[8 * j + 2 * q + 1] = __uint_as_float(v[q] & 0xFFFF0000u);
+            }
+        }
+    }
+    static FP8MI_DEVICE float load1(const void *in, int64_t i)
+    {
+        return __uint_as_float((uint32_t)((const uint16_t *)in)[i] << 16);
+    }
+};
+
+template <int IN, int MODE>
+__global__ __launch_bounds__(kBlock) void encode_kernel(const void *__restrict__ in, uint8_t *__restrict__ out,
+                                                         const float *__restrict__ prescale, int64_t count)
+{
+    const bool has_ps = prescale != nullptr;
+    const float ps = has_ps ? prescale[0] : 1.0f;
+    const int64_t n16 = count >> 4;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    u32x4 *out4 = (u32x4 *)out;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += stride) {
+        float f[16];
+        InVec<IN>::load(in, i, f);
+        u32x4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = f[4 * j + q];
+                if (has_ps) v = v * ps;  // float32 multiply, as `inp * scale` (fp8_mps_native.py:179)
+                acc |= encode_bits<MODE>(v) << (8 * q);
+            }
+            w[j] = acc;
+        }
+        out4[i] = w;
+    }
+    if (blockIdx.x == 0) {
+        int64_t i = (n16 << 4) + threadIdx.x;
+        if (i < count) {
+            float v = InVec<IN>::load1(in, i);
+            if (has_ps) v = v * ps;
+            out[i] = (uint8_t)encode_bits<MODE>(v);
+        }
+    }
+}
+
+template <int IN, int MODE>
+__global__ __launch_bounds__(kBlock) void encode_scalar_kernel(const void *__restrict__ in, uint8_t *__restrict__ out,
+                                                                const float *__restrict__ prescale, int64_t count)
+{
+    const bool has_ps = prescale != nullptr;
+    const float ps = has_ps ? prescale[0] : 1.0f;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) {
+        float v = InVec<IN>::load1(in, i);
+        if (has_ps) v = v * ps;
+        out[i] = (uint8_t)encode_bits<MODE>(v);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// amax: |x| max as float bits through atomicMax on the (non-negative) pattern
+// ---------------------------------------------------------------------------
+template <int IN>
+__global__ __launch_bounds__(kBlock) void amax_kernel(const void *__restrict__ in, uint32_t *__restrict__ out_bits,
+                                                       int64_t count, int vec_ok)
+{
+    float m = 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t n16 = vec_ok ? (count >> 4) : 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += stride) {
+        float f[16];
+        InVec<IN>::load(in, i, f);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) m = fmaxf(m, fabsf(f[j]));  // fmaxf drops NaN operands
+    }
+    for (int64_t i = (n16 << 4) + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride)
+        m = fmaxf(m, fabsf(InVec<IN>::load1(in, i)));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    __shared__ float wmax[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float b = wmax[0];
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; ++w) b = fmaxf(b, wmax[w]);
+        atomicMax(out_bits, __float_as_uint(b));
+    }
+}
+
+// scales[0] = 448/amax (double division, as the reference's Python float
+// arithmetic, fp8_mps_native.py:174-176), scales[1] = float(1/scale) (:189).
+__global__ void quant_scale_kernel(float *scales /* in: [0] = amax */)
+{
+    double amax = (double)scales[0];
+    double scale = amax > 0.0 ? 448.0 / amax : 1.0;
+    scales[0] = (float)scale;
+    scales[1] = (float)(1.0 / scale);
+}
+
+int grid_for(int64_t work_items)
+{
+    int64_t g = (work_items + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > kMaxGrid) g = kMaxGrid;
+    return (int)g;
+}
+
+bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// host launchers (called from fp8mi_api.hip)
+// ---------------------------------------------------------------------------
+int fp8mi_launch_dequant(const uint8_t *in, void *out, const float *scale, int64_t count, int out_dtype,
+                         hipStream_t s)
+{
+    if (count == 0) return 0;
+    const bool vec = aligned16(in) && aligned16(out);
+    const int grid = grid_for(vec ? (count >> 4) : count);
+#define FP8MI_DQ(OUT)                                                                              \
+    do {                                                                                           \
+        if (vec) hipLaunchKernelGGL(dequant_kernel<OUT>, dim3(grid), dim3(kBlock), 0, s, in, out, scale, count); \
+        else hipLaunchKernelGGL(dequant_scalar_kernel<OUT>, dim3(grid), dim3(kBlock), 0, s, in, out, scale, count); \
+    } while (0)
+    if (out_dtype == FP8MI_F16) FP8MI_DQ(FP8MI_F16);
+    else if (out_dtype == FP8MI_F32) FP8MI_DQ(FP8MI_F32);
+    else FP8MI_DQ(FP8MI_BF16);
+#undef FP8MI_DQ
+    return (int)hipGetLastError();
+}
+
+template <int IN>
+static int launch_encode_in(const void *in, uint8_t *out, const float *prescale, int64_t count, int mode,
+                            hipStream_t s)
+{
+    const bool vec = aligned16(in) && aligned16(out);
+    const int grid = grid_for(vec ? (count >> 4) : count);
+    if (mode == FP8MI_ENC_REFERENCE) {
+        if (vec) hipLaunchKernelGGL((encode_kernel<IN, FP8MI_ENC_REFERENCE>), dim3(grid), dim3(kBlock), 0, s, in, out, prescale, count);
+        else hipLaunchKernelGGL((encode_scalar_kernel<IN, FP8MI_ENC_REFERENCE>), dim3(grid), dim3(kBlock), 0, s, in, out, prescale, count);
+    } else {
+        if (vec) hipLaunchKernelGGL((encode_kernel<IN, FP8MI_ENC_RNE>), dim3(grid), dim3(kBlock), 0, s, in, out, prescale, count);
+        else hipLaunchKernelGGL((encode_scalar_kernel<IN, FP8MI_ENC_RNE>), dim3(grid), dim3(kBlock), 0, s, in, out, prescale, count);
+    }
+    return (int)hipGetLastError();
+}
+
+int fp8mi_launch_encode(const void *in, int in_dtype, uint8_t *out, const float *prescale, int64_t count, int mode,
+                        hipStream_t s)
+{
+    if (count == 0) return 0;
+    if (in_dtype == FP8MI_F32) return launch_encode_in<FP8MI_F32>(in, out, prescale, count, mode, s);
+    if (in_dtype == FP8MI_F16) return launch_encode_in<FP8MI_F16>(in, out, prescale, count, mode, s);
+    return launch_encode_in<FP8MI_BF16>(in, out, prescale, count, mode, s);
+}
+
+int fp8mi_launch_amax(const void *in, int in_dtype, float *out, int64_t count, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    if (count == 0) return 0;
+    const int vec = aligned16(in) ? 1 : 0;
+    const int grid = grid_for(vec ? ((count >> 4) > 0 ? (count >> 4) : 1) : count);
+    uint32_t *ob = (uint32_t *)out;
+    if (in_dtype == FP8MI_F32) hipLaunchKernelGGL(amax_kernel<FP8MI_F32>, dim3(grid), dim3(kBlock), 0, s, in, ob, count, vec);
+    else if (in_dtype == FP8MI_F16) hipLaunchKernelGGL(amax_kernel<FP8MI_F16>, dim3(grid), dim3(kBlock), 0, s, in, ob, count, vec);
+    else hipLaunchKernelGGL(amax_kernel<FP8MI_BF16>, dim3(grid), dim3(kBlock), 0, s, in, ob, count, vec);
+    return (int)hipGetLastError();
+}
+
+int fp8mi_launch_quantize(const void *in, int in_dtype, uint8_t *out, float *scales, int64_t count, int mode,
+                          hipStream_t s)
+{
+    int rc = fp8mi_launch_amax(in, in_dtype, scales, count, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(quant_scale_kernel, dim3(1), dim3(1), 0, s, scales);
+    rc = (int)hipGetLastError();
+    if (rc) return rc;
+    return fp8mi_launch_encode(in, in_dtype, out, scales, count, mode, s);
+}

@@ -1,0 +1,107 @@
+// Shared device helpers for the fp8mi kernels (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fp8mi.h"
+
+typedef float    f32x2  __attribute__((ext_vector_type(2)));
+typedef float    f32x4  __attribute__((ext_vector_type(4)));
+typedef float    f32x16 __attribute__((ext_vector_type(16)));
+typedef int      i32x4  __attribute__((ext_vector_type(4)));
+typedef int      i32x8  __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x2  __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4  __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2  __attribute__((ext_vector_type(2)));
+
+#define FP8MI_DEVICE __device__ __forceinline__
+
+// ---------------------------------------------------------------------------
+// epilogue parameters shared by the GEMV / GEMM / generic kernels
+// ---------------------------------------------------------------------------
+struct MMParams {
+    const uint8_t *A;      // (M,K) row-major bytes
+    const uint8_t *B;      // (N,K) row-major bytes
+    void *C;               // (M,N) out_dtype
+    const float *scale_a;  // [1] or [M]
+    const float *scale_b;  // [1] or [N]
+    const void *bias;      // nullptr or [N] bias_dtype
+    const float *scale_result;  // nullptr or [1]
+    int64_t M, N, K;
+    int64_t lda, ldb, ldc;
+    int sa_row, sb_row;    // 0 per-tensor, 1 per-row
+    int out_dtype, bias_dtype;
+    int nan_zero;          // 1: NaN bytes decode to 0 (reference), 0: propagate
+};
+
+// SWAR scrub: zero every byte of w whose low 7 bits are all ones (the two
+// e4m3fn NaN patterns 0x7F / 0xFF), i.e. the reference's decode rule
+// "NaN -> 0.0" (fp8_matmul.metal:21) applied to four packed bytes.
+FP8MI_DEVICE uint32_t scrub_nan4(uint32_t w)
+{
+    uint32_t n = ~(w | 0x80808080u);            // NaN byte -> 0x00, else 0x01..0x7F
+    uint32_t m = ~((n + 0x7F7F7F7Fu) | 0x7F7F7F7Fu);  // 0x80 where the byte of n is zero
+    m = m | (m - (m >> 7));                     // 0xFF where NaN
+    return w & ~m;
+}
+
+// true if any of the four bytes is a NaN pattern
+FP8MI_DEVICE bool has_nan4(uint32_t w)
+{
+    uint32_t n = ~(w | 0x80808080u);
+    return (~((n + 0x7F7F7F7Fu) | 0x7F7F7F7Fu)) != 0u;
+}
+
+// one byte -> float, reference semantics (fp8_matmul.metal:19-40): used by the
+// slow paths only; the hot kernels decode with v_cvt_pk_f32_fp8 / MFMA.
+FP8MI_DEVICE float decode_ref(uint32_t b)
+{
+    if ((b & 0x7Fu) == 0x7Fu) return 0.0f;
+    // place sign|exp|mant into float bits with the exponent field low, then
+    // rescale by 2^120 (bias 127 -> 7); exact for normals and subnormals.
+    uint32_t bits = ((b & 0x80u) << 24) | ((b & 0x7Fu) << 20);
+    return __uint_as_float(bits) * 0x1p120f;
+}
+
+FP8MI_DEVICE float load_as_float(const void *p, int64_t i, int dtype)
+{
+    if (dtype == FP8MI_F32) return ((const float *)p)[i];
+    if (dtype == FP8MI_F16) return (float)((const _Float16 *)p)[i];
+    return (float)((const __bf16 *)p)[i];
+}
+
+FP8MI_DEVICE void store_from_float(void *p, int64_t i, float v, int dtype)
+{
+    if (dtype == FP8MI_F32) ((float *)p)[i] = v;
+    else if (dtype == FP8MI_F16) ((_Float16 *)p)[i] = (_Float16)v;
+    else ((__bf16 *)p)[i] = (__bf16)v;
+}
+
+// The reference epilogue, in its order (fp8_matmul.metal:144-146 then
+// fp8_mps_patch.py:94-104): (sum * sa) * sb, + bias, * scale_result, cast.
+FP8MI_DEVICE float epilogue_value(float sum, float sa, float sb, bool has_bias, float bias,
+                                  bool has_sr, float sr)
+{
+    float r = (sum * sa) * sb;
+    if (has_bias) r = r + bias;
+    if (has_sr) r = r * sr;
+    return r;
+}
+
+// wave64 all-lanes sum
+FP8MI_DEVICE float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// launchers implemented in the .hip files (host side, internal linkage by name)
+int fp8mi_launch_gemv(const MMParams &p, hipStream_t s);
+bool fp8mi_gemv_supported(const MMParams &p);
+int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s);
+bool fp8mi_gemm_supported(const MMParams &p);
+int fp8mi_launch_generic(const MMParams &p, hipStream_t s);
+int fp8mi_launch_skinny(const MMParams &p, hipStream_t s);
+bool fp8mi_skinny_supported(const MMParams &p);

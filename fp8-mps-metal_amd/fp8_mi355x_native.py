@@ -1,0 +1,232 @@
+"""
+FP8 e4m3fn ops on MI355X: the op layer between the monkey-patch
+(fp8_mps_patch.py) and the HIP kernels (libfp8mi.so through fp8_mi355x_lib).
+
+It mirrors the reference's op module fp8_mps_native.py function for function -
+same names, same argument meaning, same error behaviour - so that code and
+tests written against the reference read the same here:
+
+  fp8_scaled_mm       fp8_mps_native.py:41-95
+  fp8_dequantize      fp8_mps_native.py:98-124
+  fp8_encode          fp8_mps_native.py:127-155
+  fp8_quantize        fp8_mps_native.py:158-190
+  fp8_scaled_mm_auto  fp8_mps_native.py:193-210
+  fp8_scaled_mm_fast  fp8_mps_native.py:213-267 (kept as an alias: the
+                      dequant -> fp16 matmul detour it implemented exists only
+                      because Apple GPUs have no FP8 ALU; on gfx950 the MFMA
+                      kernel consumes the bytes directly)
+
+What differs, deliberately:
+  * the device is "cuda" (PyTorch-ROCm's name for HIP devices), not "mps";
+  * kernels are launched on torch's CURRENT stream of the tensor's device and
+    never synchronise (the reference's `.item()` in fp8_quantize,
+    fp8_mps_native.py:174, is gone: amax, scale and encode all stay on the GPU);
+  * bias / scale_result / out_dtype can be passed down and are fused into the
+    kernel epilogue (the reference applies them as three extra passes,
+    fp8_mps_patch.py:94-104);
+  * a per-row scale next to a per-tensor scale is broadcast properly (the
+    reference reads out of bounds in that case, fp8_mps_native.py:73 with
+    fp8_matmul.metal:144-146);
+  * there is no CPU path.  A tensor that is not on a HIP device is moved there
+    (as the reference moves to "mps", fp8_mps_native.py:63-66); without a GPU
+    that raises.
+"""
+
+from __future__ import annotations
+
+import torch
+
+import fp8_mi355x_lib as _l
+
+DEVICE_TYPE = "cuda"  # PyTorch-ROCm reports HIP devices as "cuda"
+
+_DTYPE_CODE = {torch.float32: _l.F32, torch.float16: _l.F16, torch.bfloat16: _l.BF16}
+
+# process-wide defaults; see include/fp8mi.h for the meaning of the modes
+NAN_MODE = _l.NAN_ZERO          # reference decode: NaN bytes are 0.0
+ENCODE_MODE = _l.ENC_REFERENCE  # reference encode rules
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _to_device(t: torch.Tensor) -> torch.Tensor:
+    return t if t.device.type == DEVICE_TYPE else t.to(DEVICE_TYPE)
+
+
+def _scale_arg(scale, device, rows: int, what: str):
+    """-> (float32 contiguous tensor on `device`, mode).  1 element = per-tensor,
+    `rows` elements (any shape, e.g. (M,1) / (1,N)) = per-row."""
+    s = scale.to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+    if s.numel() == 1:
+        return s, _l.SCALE_TENSOR
+    if s.numel() == rows:
+        return s, _l.SCALE_ROW
+    raise AssertionError(f"{what} has {s.numel()} elements; expected 1 or {rows}")
+
+
+def fp8_scaled_mm(A: torch.Tensor, B: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,
+                  *, bias: torch.Tensor | None = None, scale_result: torch.Tensor | None = None,
+                  out_dtype: torch.dtype | None = None, nan_mode: int | None = None,
+                  kernel: int = _l.KERNEL_AUTO) -> torch.Tensor:
+    """FP8 scaled matrix multiplication on the GPU.
+
+    A: (M, K) uint8 - e4m3fn bytes, row-major
+    B: (N, K) uint8 - e4m3fn bytes, row-major (i.e. pre-transposed); a row
+       stride larger than K is accepted without a copy
+    scale_a: [1] or [M] float32;  scale_b: [1] or [N] float32
+    Returns (M, N) float32 (or `out_dtype`) on the device:
+        ((A_dec @ B_dec.T) * scale_a * scale_b + bias) * scale_result
+    Same contract as fp8_mps_native.py:41-95 (asserts included); the kernel is
+    picked by shape inside the library (GEMV for M == 1, MFMA GEMM otherwise).
+    """
+    assert A.dtype == torch.uint8 and B.dtype == torch.uint8
+    assert A.dim() == 2 and B.dim() == 2
+    M, K = A.shape
+    N = B.shape[0]
+    assert B.shape[1] == K
+
+    A = _to_device(A)
+    B = _to_device(B)
+    dev = A.device
+    assert B.device == dev, "A and B must be on the same device"
+    # rows must be dense in K; a padded row stride is fine (no copy)
+    if not (K == 0 or M == 0 or (A.stride(1) == 1 and A.stride(0) >= K) or (M == 1 and A.stride(1) == 1)):
+        A = A.contiguous()
+    if not (K == 0 or N == 0 or (B.stride(1) == 1 and B.stride(0) >= K) or (N == 1 and B.stride(1) == 1)):
+        B = B.contiguous()
+    lda = max(A.stride(0), K) if M > 1 else max(K, 1)
+    ldb = max(B.stride(0), K) if N > 1 else max(K, 1)
+
+    sa, sa_mode = _scale_arg(scale_a, dev, M, "scale_a")
+    sb, sb_mode = _scale_arg(scale_b, dev, N, "scale_b")
+
+    out_dtype = torch.float32 if out_dtype is None else out_dtype
+    if out_dtype not in _DTYPE_CODE:
+        raise AssertionError(f"unsupported out_dtype {out_dtype}")
+    C = torch.empty(M, N, dtype=out_dtype, device=dev)
+    if M == 0 or N == 0:
+        return C
+
+    bias_ptr, bias_code = None, _l.F32
+    if bias is not None:
+        bias = bias.to(device=dev)
+        if bias.dtype not in _DTYPE_CODE:
+            bias = bias.to(torch.float32)
+        bias = bias.reshape(-1).contiguous()
+        assert bias.numel() == N, f"bias has {bias.numel()} elements; expected {N}"
+        bias_ptr, bias_code = bias.data_ptr(), _DTYPE_CODE[bias.dtype]
+    sr_ptr = None
+    if scale_result is not None:
+        scale_result = scale_result.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        assert scale_result.numel() == 1, "scale_result must have one element"
+        sr_ptr = scale_result.data_ptr()
+
+    lib = _l.load()
+    with torch.cuda.device(dev):
+        rc = lib.fp8mi_scaled_mm_ex(
+            A.data_ptr(), B.data_ptr(), C.data_ptr(), sa.data_ptr(), sb.data_ptr(), bias_ptr, sr_ptr,
+            M, N, K, lda, ldb, N, sa_mode, sb_mode, _DTYPE_CODE[out_dtype], bias_code,
+            NAN_MODE if nan_mode is None else nan_mode, kernel, _stream(dev))
+    _l.check(rc, "fp8mi_scaled_mm")
+    return C
+
+
+def fp8_dequantize(input: torch.Tensor, scale: torch.Tensor | None = None,
+                   out_dtype: torch.dtype = torch.float16) -> torch.Tensor:
+    """FP8 -> half dequantisation on the GPU (fp8_mps_native.py:98-124).
+
+    input: uint8 tensor (e4m3fn bytes);  scale: scalar tensor or None.
+    Returns float16 (or `out_dtype`) of the same shape:
+    half(decode(b)) * half(scale), the product formed in float16 as in the
+    reference; float32 / bfloat16 outputs convert that half value.
+    """
+    input = _to_device(input)
+    assert input.dtype == torch.uint8
+    dev = input.device
+    src = input.contiguous()
+    out = torch.empty(input.shape, dtype=out_dtype, device=dev)
+    count = src.numel()
+    if count == 0:
+        return out
+    s_ptr = None
+    if scale is not None:
+        scale = scale.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        assert scale.numel() == 1, "scale must be a scalar"
+        s_ptr = scale.data_ptr()
+    lib = _l.load()
+    with torch.cuda.device(dev):
+        rc = lib.fp8mi_dequant(src.data_ptr(), out.data_ptr(), s_ptr, count, _DTYPE_CODE[out_dtype], _stream(dev))
+    _l.check(rc, "fp8mi_dequant")
+    return out
+
+
+def _encode_source(input: torch.Tensor) -> torch.Tensor:
+    inp = _to_device(input)
+    if inp.dtype not in _DTYPE_CODE:  # ints, float64 ...: the reference converts to float32 first
+        inp = inp.to(torch.float32)
+    return inp.contiguous()
+
+
+def fp8_encode(input: torch.Tensor, encode_mode: int | None = None) -> torch.Tensor:
+    """Float -> FP8 bytes without scaling (fp8_mps_native.py:127-155): values
+    keep their magnitude, saturating at +-448.  Used by .to(float8_e4m3fn) and
+    .copy_().  float16 / bfloat16 sources are widened inside the kernel.
+    Returns uint8 of the same shape."""
+    inp = _encode_source(input)
+    dev = inp.device
+    out = torch.empty(inp.shape, dtype=torch.uint8, device=dev)
+    count = inp.numel()
+    if count == 0:
+        return out
+    lib = _l.load()
+    with torch.cuda.device(dev):
+        rc = lib.fp8mi_encode(inp.data_ptr(), _DTYPE_CODE[inp.dtype], out.data_ptr(), None, count,
+                              ENCODE_MODE if encode_mode is None else encode_mode, _stream(dev))
+    _l.check(rc, "fp8mi_encode")
+    return out
+
+
+def fp8_quantize(input: torch.Tensor, encode_mode: int | None = None):
+    """Float -> FP8 with automatic amax scaling (fp8_mps_native.py:158-190).
+
+    Returns (uint8 tensor, inverse_scale[1] float32) with
+    scale = 448 / max|input|; everything (amax, scale, encode) runs on the
+    device, no host read-back."""
+    inp = _encode_source(input)
+    dev = inp.device
+    out = torch.empty(inp.shape, dtype=torch.uint8, device=dev)
+    scales = torch.empty(2, dtype=torch.float32, device=dev)
+    lib = _l.load()
+    with torch.cuda.device(dev):
+        rc = lib.fp8mi_quantize(inp.data_ptr(), _DTYPE_CODE[inp.dtype], out.data_ptr(), scales.data_ptr(),
+                                inp.numel(), ENCODE_MODE if encode_mode is None else encode_mode, _stream(dev))
+    _l.check(rc, "fp8mi_quantize")
+    return out, scales[1:2]
+
+
+def fp8_amax(input: torch.Tensor) -> torch.Tensor:
+    """max|input| as a float32[1] device tensor (no host sync)."""
+    inp = _encode_source(input)
+    dev = inp.device
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    lib = _l.load()
+    with torch.cuda.device(dev):
+        rc = lib.fp8mi_amax(inp.data_ptr(), _DTYPE_CODE[inp.dtype], out.data_ptr(), inp.numel(), _stream(dev))
+    _l.check(rc, "fp8mi_amax")
+    return out
+
+
+def fp8_scaled_mm_auto(A, B, scale_a, scale_b, **kw):
+    """Shape-based strategy choice (fp8_mps_native.py:193-210).  The reference
+    switches at M <= 16 between its fused kernel and a dequant + fp16 matmul;
+    here the choice (GEMV / MFMA GEMM tile shape / generic) is made inside
+    fp8mi_scaled_mm from M, N, K and alignment."""
+    return fp8_scaled_mm(A, B, scale_a, scale_b, **kw)
+
+
+# The reference's "fast" path (fp8_mps_native.py:213-267) dequantises both
+# operands to fp16 and calls the native matmul.  On gfx950 that would be slower
+# and less accurate than the fp8 MFMA kernel, so the name maps to the same op.
+fp8_scaled_mm_fast = fp8_scaled_mm

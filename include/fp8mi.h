@@ -1,0 +1,177 @@
+/*
+ * fp8mi - MI355X (gfx950) FP8 e4m3fn scaled-matmul and cast kernels, C ABI.
+ *
+ * This is the drop-in boundary of the build: a shared library
+ * (fp8-mps-metal_amd/libfp8mi.so) with plain-C entry points - device pointers,
+ * sizes and a HIP stream; no torch or C++ types - that a host binds with
+ * ctypes / cgo / JNI.  It is the MI355X-native counterpart of the reference's
+ * pybind11 module `fp8_metal` (fp8_bridge.cpp:361-371) and of the four kernel
+ * launch sites of fp8_mps_native.py, but pointer-level: nothing is staged
+ * through the CPU, nothing is allocated, nothing synchronises.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer on the current HIP device unless said
+ *     otherwise; `stream` is a hipStream_t passed as void* (NULL = default);
+ *   - every call only ENQUEUES work on `stream` and returns; it never blocks,
+ *     never allocates, and is safe to capture into a HIP graph;
+ *   - return value 0 = ok; negative = argument error (FP8MI_E_*); positive =
+ *     a hipError_t from the launch.  fp8mi_last_error() returns a
+ *     thread-local, human-readable message for the last non-zero return;
+ *   - the library is stateless (no globals besides that message), so calls
+ *     are re-entrant from any thread;
+ *   - all element counts are 64-bit (the reference's `uint count`,
+ *     fp8_matmul.metal:218,231, caps at 2^32-1).
+ *
+ * Semantics are the REFERENCE's (audiohacking/fp8-mps-metal), not OCP/torch's,
+ * wherever they differ; the non-default modes give the OCP behaviour:
+ *   decode: NaN bytes 0x7F/0xFF -> +0.0              (fp8_matmul.metal:21)
+ *   encode: clamp-not-carry, flush below 2^-9, saturate to 0x7E, -0.0 -> 0x00
+ *                                                    (fp8_matmul.metal:44-92)
+ */
+#ifndef FP8MI_H
+#define FP8MI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FP8MI_VERSION 0x000100 /* 0.1.0 */
+
+/* element types of non-fp8 operands */
+enum { FP8MI_F32 = 0, FP8MI_F16 = 1, FP8MI_BF16 = 2 };
+
+/* scale layouts */
+enum { FP8MI_SCALE_TENSOR = 0, /* one float                               */
+       FP8MI_SCALE_ROW = 1 };  /* one float per row of A (M) / of B (N)   */
+
+/* what a NaN byte (0x7F / 0xFF) in A or B means */
+enum { FP8MI_NAN_ZERO = 0,       /* reference: decodes to +0.0 (fp8_matmul.metal:21)   */
+       FP8MI_NAN_PROPAGATE = 1 };/* OCP / torch: NaN, poisons its dot products        */
+
+/* float -> fp8 rounding/saturation rules */
+enum { FP8MI_ENC_REFERENCE = 0,  /* fp8_matmul.metal:44-92 (see header comment)        */
+       FP8MI_ENC_RNE = 1 };      /* OCP round-to-nearest-even, overflow -> NaN (torch) */
+
+/* kernel selection for fp8mi_scaled_mm_ex (testing / benchmarking) */
+enum { FP8MI_KERNEL_AUTO = 0,
+       FP8MI_KERNEL_GEMV = 1,      /* M == 1 wavefront-reduced vec-mat                */
+       FP8MI_KERNEL_GEMM_128 = 2,  /* 128x128x128 LDS-tiled fp8 MFMA                  */
+       FP8MI_KERNEL_GENERIC = 3,   /* any shape / alignment, one wave per output      */
+       FP8MI_KERNEL_GEMM_256 = 4,  /* 256x256x128 LDS-tiled fp8 MFMA (large M,N)      */
+       FP8MI_KERNEL_GEMM_128x64 = 5,
+       FP8MI_KERNEL_SKINNY = 6 };  /* 2 <= M <= 16 weight-streaming MFMA              */
+
+/* error codes (negative returns) */
+enum { FP8MI_OK = 0,
+       FP8MI_E_NULL = -1,     /* required pointer is NULL                  */
+       FP8MI_E_SHAPE = -2,    /* negative size or leading dim too small    */
+       FP8MI_E_ENUM = -3,     /* unknown dtype / mode / kernel             */
+       FP8MI_E_UNSUPPORTED = -4 /* forced kernel cannot run this problem   */ };
+
+/*
+ * C[m,n] = cast( ((sum_k dec(A[m,k]) * dec(B[n,k])) * sa * sb + bias[n]) * scale_result )
+ *
+ * Replaces: fp8_scaled_matmul_kernel (fp8_matmul.metal:99-147),
+ *           fp8_scaled_vecmat_kernel (fp8_matmul.metal:155-210), their launch
+ *           sites fp8_mps_native.py:41-95 / fp8_bridge.cpp:165-259, the kernel
+ *           choice fp8_scaled_mm_auto (fp8_mps_native.py:193-210) and the three
+ *           elementwise passes of the epilogue in fp8_mps_patch.py:94-104
+ *           (fused here, same order: + bias, * scale_result, cast).
+ *
+ * A        (M,K) fp8 e4m3fn bytes, row-major, leading dimension lda >= K
+ * B_nk     (N,K) fp8 e4m3fn bytes, row-major (i.e. torch's column-major
+ *          `other` (K,N) seen through .t()), leading dimension ldb >= K
+ * C        (M,N) out_dtype, row-major, leading dimension ldc >= N (elements)
+ * scale_a  float[1] (FP8MI_SCALE_TENSOR) or float[M] (FP8MI_SCALE_ROW)
+ * scale_b  float[1] or float[N]
+ * bias     NULL or [N] of bias_dtype;  scale_result NULL or float[1]
+ * Accumulation is float32.  M == 0 or N == 0 is a no-op; K == 0 writes the
+ * epilogue of a zero sum.
+ */
+int fp8mi_scaled_mm(const uint8_t *A, const uint8_t *B_nk, void *C,
+                    const float *scale_a, const float *scale_b,
+                    const void *bias, const float *scale_result,
+                    int64_t M, int64_t N, int64_t K,
+                    int64_t lda, int64_t ldb, int64_t ldc,
+                    int scale_a_mode, int scale_b_mode,
+                    int out_dtype, int bias_dtype, int nan_mode,
+                    void *stream);
+
+/* Same, with the kernel forced (FP8MI_KERNEL_*); FP8MI_E_UNSUPPORTED if the
+ * forced kernel cannot run the problem (e.g. GEMV with M != 1). */
+int fp8mi_scaled_mm_ex(const uint8_t *A, const uint8_t *B_nk, void *C,
+                       const float *scale_a, const float *scale_b,
+                       const void *bias, const float *scale_result,
+                       int64_t M, int64_t N, int64_t K,
+                       int64_t lda, int64_t ldb, int64_t ldc,
+                       int scale_a_mode, int scale_b_mode,
+                       int out_dtype, int bias_dtype, int nan_mode,
+                       int kernel, void *stream);
+
+/*
+ * out[i] = cast( half(dec(in[i])) * half(scale) )      (scale NULL = no multiply)
+ *
+ * Replaces: fp8_to_half_kernel (fp8_matmul.metal:215-223) + the separate
+ *           `output * scale.to(float16)` pass of fp8_dequantize
+ *           (fp8_mps_native.py:98-124; fp8_bridge.cpp:265-306).  The product
+ *           is formed in float16 exactly as there; out_dtype F32/BF16 then
+ *           widens/rounds that half (the reference's `.to(dtype)`,
+ *           fp8_mps_patch.py:219-221).
+ */
+int fp8mi_dequant(const uint8_t *in, void *out, const float *scale,
+                  int64_t count, int out_dtype, void *stream);
+
+/*
+ * out[i] = enc( float32(in[i]) * prescale )            (prescale NULL = no multiply)
+ *
+ * Replaces: float_to_fp8_kernel (fp8_matmul.metal:228-236) and its launch in
+ *           fp8_encode (fp8_mps_native.py:127-155; value-preserving, used by
+ *           .to()/.copy_(), fp8_mps_patch.py:191,283); with `prescale` also
+ *           the `inp * scale` pass of fp8_quantize (fp8_mps_native.py:179).
+ *           f16/bf16 inputs are widened in-kernel (the reference converts to
+ *           float32 first, fp8_mps_native.py:142).
+ */
+int fp8mi_encode(const void *in, int in_dtype, uint8_t *out, const float *prescale,
+                 int64_t count, int encode_mode, void *stream);
+
+/* *out = max_i |in[i]| as float32 (0 for count == 0; NaNs are ignored).
+ * Replaces: `inp.abs().max().item()` of fp8_quantize (fp8_mps_native.py:174)
+ * without the host read-back. */
+int fp8mi_amax(const void *in, int in_dtype, float *out, int64_t count, void *stream);
+
+/*
+ * Amax-scaled quantisation, entirely on the device (no host sync):
+ *   amax = max|in|; scale = amax > 0 ? 448/amax : 1   (evaluated in double)
+ *   out[i] = enc(float32(in[i]) * float32(scale));  scales[0] = scale,
+ *   scales[1] = float32(1/scale)  (the inverse scale _scaled_mm consumes)
+ * Replaces: fp8_quantize (fp8_mps_native.py:158-190; fp8_bridge.cpp:312-356).
+ * `scales` is float[2] device memory owned by the caller.
+ */
+int fp8mi_quantize(const void *in, int in_dtype, uint8_t *out, float *scales,
+                   int64_t count, int encode_mode, void *stream);
+
+typedef struct fp8mi_device_info {
+    int compute_units;       /* multiProcessorCount                       */
+    int clock_khz;           /* max engine clock                          */
+    int memory_clock_khz;
+    int memory_bus_bits;
+    int l2_bytes;
+    int lds_bytes_per_cu;    /* maxSharedMemoryPerMultiProcessor          */
+    int wavefront_size;
+    int64_t total_memory;
+    char arch[64];           /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
+    char name[128];
+} fp8mi_device_info_t;
+
+/* Host-side query of HIP device `device` (for the roofline harness). */
+int fp8mi_device_info(int device, fp8mi_device_info_t *out);
+
+int fp8mi_version(void);
+const char *fp8mi_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FP8MI_H */
