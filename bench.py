@@ -1,0 +1,371 @@
+#!/usr/bin/env python3
+"""
+bench.py - measurement harness for the FP8 e4m3fn hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload auto|gemm|gemv|flux|quantize|dequant]
+
+Prints ONE JSON line (rank 0).  A "step" is one pass of the hot path over one
+batch of synthetic inputs that are already resident in HBM: `inner` back-to-back
+launches of the C-ABI entry point (fp8mi_scaled_mm / fp8mi_encode /
+fp8mi_dequant), each on a DIFFERENT weight buffer out of a rotating set larger
+than the 256 MiB Infinity Cache, so weights stream from HBM as they do in a
+model whose layers are visited once per forward.  The batch is replayed as a HIP
+graph, so the number is not bounded by Python launch overhead.
+
+Workloads (BASELINE.json configs):
+  gemm     M=512, K=N=4096, fp32 out   (configs[2]; the N=1 default, TFLOP/s)
+  gemv     M=1, K=14336, N=4096        (configs[1]; GB/s of algorithmic bytes)
+  flux     M=4096, K=3072, N=12288, bf16 out (configs[3]); with --gpus N > 1 the
+           N dimension is column-sharded over the ranks and the output is
+           all-gathered over RCCL/xGMI ("strong" scaling: fixed total work)
+  quantize / dequant   2^30 elements   (configs[4])
+
+Two objects ride on the line: `roofline` for the dominant kernel - algorithmic
+flops or bytes per launch / the kernel's average DEVICE duration, the latter
+measured live with per-dispatch HIP events (fp8mi_profile_begin/_end, the
+timestamps rocprofv3 --kernel-trace reads) - and `cpu_baseline`, the C oracle
+(oracle/fp8_oracle.c, OpenMP) timed on this box's host cores on a bounded
+sample of the same workload.  The oracle is only ever the baseline / checker.
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "fp8-mps-metal_amd")
+ORACLE = os.path.join(ROOT, "oracle")
+for _p in (PKG, ORACLE):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import fp8_mi355x_lib as L  # noqa: E402
+
+METRIC = "FP8 _scaled_mm TFLOPS (M>=4) + GEMV HBM GB/s (M=1) vs roofline, 1/8 GPU"
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP8_FLOP_PER_CLK_CU = 8192     # dense fp8 MFMA (f8f6f4 K=128 path): 5.03 PFLOP/s at 256 CU x 2.4 GHz
+CACHE_BYTES = 256 << 20        # Infinity Cache
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def clean_bytes(shape, dev, gen):
+    """Uniform random e4m3 bytes with the two NaN patterns remapped (0x7F->0x7E,
+    0xFF->0xFE): throughput inputs per SURVEY 8d; NaN-byte parity is a test."""
+    b = torch.randint(0, 256, shape, dtype=torch.uint8, device=dev, generator=gen)
+    return torch.where((b & 0x7F) == 0x7F, b ^ 1, b)
+
+
+class Workload:
+    """One named workload: buffers + a `launch(i)` closure calling the C ABI."""
+
+    def __init__(self, name, dev, world=1, rank=0, kernel=L.KERNEL_AUTO):
+        self.name, self.dev, self.world, self.rank, self.kernel = name, dev, world, rank, kernel
+        self.lib = L.load()
+        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        self.collective = None
+        if name in ("gemm", "gemv", "flux"):
+            M, K, N = {"gemm": (512, 4096, 4096), "gemv": (1, 14336, 4096), "flux": (4096, 3072, 12288)}[name]
+            self.M, self.K, self.N_total = M, K, N
+            Nl = N // world
+            assert N % world == 0
+            self.N = Nl
+            self.out_dtype = torch.bfloat16 if name == "flux" else torch.float32
+            esz = 2 if name == "flux" else 4
+            nbuf = max(2, -(-int(1.25 * CACHE_BYTES) // (Nl * K)))
+            self.A = clean_bytes((M, K), dev, torch.Generator(device=dev).manual_seed(99))  # replicated activations
+            self.Bs = [clean_bytes((Nl, K), dev, gen) for _ in range(nbuf)]
+            self.sa = torch.full((1,), 0.01, dtype=torch.float32, device=dev)
+            self.sb = torch.full((1,), 0.01, dtype=torch.float32, device=dev)
+            self.flops = 2.0 * M * Nl * K
+            self.bytes = float(M * K + Nl * K + esz * M * Nl)
+            self.unit_flops = name != "gemv"
+            self.inner = nbuf * (4 if name == "gemv" else 1)
+            if world > 1:
+                # rank r computes C^T[r] = B_r . A^T (N/w x M, row-major) so that the
+                # all-gather along dim 0 lands the full C^T (N x M) contiguously;
+                # C is its .t() view - no post-gather shuffle.
+                self.Cs = [torch.empty(Nl, M, dtype=self.out_dtype, device=dev) for _ in range(2)]
+                self.Cfull = [torch.empty(N, M, dtype=self.out_dtype, device=dev) for _ in range(2)]
+            else:
+                self.Cs = [torch.empty(M, Nl, dtype=self.out_dtype, device=dev) for _ in range(2)]
+            self.code = L.BF16 if name == "flux" else L.F32
+            self.desc = {"workload": f"{name}: M={M} K={K} N={N} e4m3fn, per-tensor scales, "
+                                     f"{'bf16' if name == 'flux' else 'fp32'} out, {nbuf} rotating weight buffers",
+                         "M": M, "K": K, "N": N}
+        elif name in ("quantize", "dequant"):
+            n = 1 << 30
+            self.count = n
+            if name == "quantize":
+                self.src = [torch.randn(n, device=dev, generator=gen) * 16 for _ in range(1)]
+                self.dst = [torch.empty(n, dtype=torch.uint8, device=dev)]
+                self.bytes = 5.0 * n
+            else:
+                self.src = [clean_bytes((n,), dev, gen)]
+                self.dst = [torch.empty(n, dtype=torch.float16, device=dev)]
+                self.bytes = 3.0 * n
+            self.flops = 0.0
+            self.unit_flops = False
+            self.inner = 2
+            self.desc = {"workload": f"{name}: 2^30 elements ({'fp32 -> e4m3fn' if name == 'quantize' else 'e4m3fn -> fp16'})",
+                         "elements": n}
+        else:
+            raise ValueError(name)
+
+    def launch(self, i, stream):
+        lib = self.lib
+        if self.name in ("gemm", "gemv", "flux"):
+            B = self.Bs[i % len(self.Bs)]
+            C = self.Cs[i % 2]
+            if self.world > 1:  # transposed product: "A" operand = weight shard, "B_nk" operand = activations
+                rc = lib.fp8mi_scaled_mm_ex(B.data_ptr(), self.A.data_ptr(), C.data_ptr(), self.sb.data_ptr(),
+                                            self.sa.data_ptr(), None, None, self.N, self.M, self.K, self.K, self.K,
+                                            self.M, 0, 0, self.code, 0, L.NAN_ZERO, self.kernel, stream)
+            else:
+                rc = lib.fp8mi_scaled_mm_ex(self.A.data_ptr(), B.data_ptr(), C.data_ptr(), self.sa.data_ptr(),
+                                            self.sb.data_ptr(), None, None, self.M, self.N, self.K, self.K, self.K,
+                                            self.N, 0, 0, self.code, 0, L.NAN_ZERO, self.kernel, stream)
+        elif self.name == "quantize":
+            rc = lib.fp8mi_encode(self.src[0].data_ptr(), L.F32, self.dst[0].data_ptr(), None, self.count,
+                                  L.ENC_REFERENCE, stream)
+        else:
+            rc = lib.fp8mi_dequant(self.src[0].data_ptr(), self.dst[0].data_ptr(), None, self.count, L.F16, stream)
+        L.check(rc, f"bench launch {self.name}")
+
+    def step(self):
+        """One step, eagerly on the current stream (also what gets captured)."""
+        s = torch.cuda.current_stream(self.dev).cuda_stream
+        for i in range(self.inner):
+            self.launch(i, s)
+            if self.world > 1:
+                dist.all_gather_into_tensor(self.Cfull[i % 2], self.Cs[i % 2])
+
+
+def time_steps(w, steps, warmup, use_graph, world):
+    dev = w.dev
+    graph = None
+    if use_graph and world == 1:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            w.step()  # warm every code path before capture
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            w.step()
+    run = graph.replay if graph is not None else w.step
+    for _ in range(warmup):
+        run()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, graph is not None
+
+
+def kernel_durations(w, launches):
+    """Average pure device duration (s) of the workload's kernel, per-dispatch events."""
+    s = torch.cuda.current_stream(w.dev).cuda_stream
+    torch.cuda.synchronize(w.dev)
+    with L.kernel_timer(launches) as kt:
+        for i in range(launches):
+            w.launch(i, s)
+    torch.cuda.synchronize(w.dev)
+    ms = sorted(kt.ms)
+    if not ms:
+        return None
+    return {"avg_s": sum(ms) / len(ms) * 1e-3, "min_s": ms[0] * 1e-3, "median_s": ms[len(ms) // 2] * 1e-3, "n": len(ms)}
+
+
+def roofline_of(w, kd, info, traffic):
+    if kd is None:
+        return None
+    if w.unit_flops:
+        peak = info["compute_units"] * (info["clock_khz"] / 1e6) * FP8_FLOP_PER_CLK_CU / 1e3  # TFLOP/s
+        ach = w.flops / kd["avg_s"] / 1e12
+        r = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s"}
+    else:
+        ach = w.bytes / kd["avg_s"] / 1e9
+        r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    r["frac"] = round(r["achieved"] / r["peak"], 4)
+    r["traffic"] = traffic
+    r["kernel_avg_us"] = round(kd["avg_s"] * 1e6, 3)
+    r["kernel_min_us"] = round(kd["min_s"] * 1e6, 3)
+    r["kernel_launches_timed"] = kd["n"]
+    r["algorithmic_per_launch"] = w.flops if w.unit_flops else w.bytes
+    return r
+
+
+def cpu_baseline(w, budget_s=12.0):
+    """The C oracle (OpenMP) on the host cores, bounded sample of the same workload."""
+    so = os.path.join(ORACLE, "libfp8_oracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", ORACLE, "-s"])
+    o = ctypes.CDLL(so)
+    o.fp8o_num_threads.restype = ctypes.c_int
+    cores = int(o.fp8o_num_threads())
+    vp, sz = ctypes.c_void_p, ctypes.c_size_t
+    import numpy as np
+    rng = np.random.default_rng(1234)
+    if w.name in ("gemm", "gemv", "flux"):
+        K, N = w.K, min(w.N_total, 4096)
+        B = rng.integers(0, 127, size=(N, K), dtype=np.uint8)
+        sa = np.array([0.01], np.float32)
+
+        def run(rows):
+            A = rng.integers(0, 127, size=(rows, K), dtype=np.uint8)
+            C = np.empty((rows, N), np.float32)
+            t0 = time.perf_counter()
+            o.fp8o_scaled_mm(A.ctypes.data_as(vp), B.ctypes.data_as(vp), C.ctypes.data_as(vp), sa.ctypes.data_as(vp),
+                             sa.ctypes.data_as(vp), sz(rows), sz(N), sz(K), sz(1), sz(1))
+            return time.perf_counter() - t0
+
+        probe_rows = 1 if w.M == 1 else 8
+        run(probe_rows)
+        t = run(probe_rows)
+        rows = w.M if w.M == 1 else int(max(probe_rows, min(w.M, probe_rows * budget_s / max(t, 1e-6))))
+        reps = max(1, int(budget_s / max(t * rows / probe_rows, 1e-6))) if w.M == 1 else 1
+        reps = min(reps, 200)
+        tt = sum(run(rows) for _ in range(reps))
+        if w.unit_flops:
+            val, unit = 2.0 * rows * N * K * reps / tt / 1e12, "TFLOP/s"
+        else:
+            val, unit = (N * K + K + 4 * N) * reps / tt / 1e9, "GB/s"
+        sample = f"{reps} x fp8o_scaled_mm (oracle/fp8_oracle.c, OpenMP) on M={rows} of {w.M} rows, K={K}, N={N}; {tt:.1f} s"
+    else:
+        n = 1 << 26
+        if w.name == "quantize":
+            x = (rng.standard_normal(n) * 16).astype(np.float32)
+            out = np.empty(n, np.uint8)
+            fn = lambda: o.fp8o_encode(x.ctypes.data_as(vp), out.ctypes.data_as(vp), sz(n))
+            per = 5.0
+        else:
+            x = rng.integers(0, 127, size=n, dtype=np.uint8)
+            out = np.empty(n, np.uint16)
+            fn = lambda: o.fp8o_dequant_f16_bits(x.ctypes.data_as(vp), out.ctypes.data_as(vp), sz(n))
+            per = 3.0
+        fn()
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < budget_s / 2 and reps < 50:
+            fn()
+            reps += 1
+        tt = time.perf_counter() - t0
+        val, unit = per * n * reps / tt / 1e9, "GB/s"
+        sample = f"{reps} x 2^26 elements of the 2^30 (oracle/fp8_oracle.c, OpenMP); {tt:.1f} s"
+    return {"value": float(f"{val:.4g}"), "unit": unit, "cores": cores, "kind": "port", "sample": sample}
+
+
+def load_traffic(name):
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(p)).get(name)
+    except Exception:
+        return None
+
+
+def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info):
+    w = Workload(name, dev, world, rank, kernel)
+    dt, graphed = time_steps(w, steps, warmup, True, world)
+    launches = steps * w.inner
+    if w.unit_flops:
+        value, unit = w.flops * world * launches / dt / 1e12, "TFLOP/s"
+    else:
+        value, unit = w.bytes * launches / dt / 1e9, "GB/s"
+    kd = kernel_durations(w, min(4 * w.inner, 256)) if world == 1 or True else None
+    res = {"value": round(value, 3), "unit": unit, "ms_per_step": round(dt / steps * 1e3, 5),
+           "launches_per_step": w.inner, "hip_graph": graphed, "config": w.desc,
+           "roofline": roofline_of(w, kd, info, load_traffic(name))}
+    if with_cpu:
+        res["cpu_baseline"] = cpu_baseline(w)
+    del w
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="auto", choices=["auto", "gemm", "gemv", "flux", "quantize", "dequant"])
+    ap.add_argument("--kernel", type=int, default=L.KERNEL_AUTO, help="force an FP8MI_KERNEL_* id")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; the product has no CPU path")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    L.load()
+    info = L.device_info(local)
+
+    primary = args.workload
+    if primary == "auto":
+        primary = "gemm" if world == 1 else "flux"
+    if world > 1 and primary != "flux":
+        raise SystemExit("multi-GPU runs shard the FLUX linear (configs[3]); use --workload flux or auto")
+
+    res = measure(primary, dev, args.steps, args.warmup, world, rank, args.kernel,
+                  with_cpu=(world == 1 and rank == 0 and not args.no_cpu_baseline), info=info)
+    line = {
+        "metric": METRIC, "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
+        "scaling": "strong" if primary == "flux" else "weak", "vs_baseline": None,
+        "dtype": "fp8_e4m3fn (fp32 accumulate)" if primary in ("gemm", "gemv", "flux") else "u8",
+        "data": "synthetic (seeded uniform e4m3 bytes, NaN patterns remapped; weights rotate through > 256 MiB)",
+        "config": dict(res["config"], launches_per_step=res["launches_per_step"], hip_graph=res["hip_graph"],
+                       parallelism=("N-column-sharded x%d + RCCL all-gather" % world) if world > 1 else "single GPU",
+                       device=info["name"], arch=info["arch"], compute_units=info["compute_units"]),
+        "roofline": res["roofline"],
+    }
+    if "cpu_baseline" in res:
+        line["cpu_baseline"] = res["cpu_baseline"]
+
+    if world == 1 and args.workload == "auto" and not args.no_secondary:
+        sec = {}
+        for name in ("gemv", "flux", "quantize", "dequant"):
+            try:
+                r = measure(name, dev, max(3, args.steps // 2), max(1, args.warmup // 2), 1, 0, L.KERNEL_AUTO,
+                            with_cpu=(name == "gemv" and not args.no_cpu_baseline), info=info)
+                sec[name] = r
+            except Exception as e:  # a secondary failure must not hide the primary number
+                sec[name] = {"error": repr(e)}
+        line["secondary"] = sec
+
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "fp8mi_common.h"
 
 int fp8mi_launch_dequant(const uint8_t *in, void *out, const float *scale, int64_t count, int out_dtype, hipStream_t s);
@@ -35,11 +37,63 @@ int hip_result(int rc, const char *what)
     return 0;
 }
 
+struct ProfileState {
+    std::vector<hipEvent_t> ev;  // start0, stop0, start1, stop1, ...
+    int used = 0;
+    bool on = false;
+};
+thread_local ProfileState g_prof;
+
 bool dtype_ok(int d) { return d == FP8MI_F32 || d == FP8MI_F16 || d == FP8MI_BF16; }
 
 }  // namespace
 
+bool fp8mi_next_profile_events(hipEvent_t *start, hipEvent_t *stop)
+{
+    ProfileState &ps = g_prof;
+    if (!ps.on || (size_t)(2 * ps.used + 1) >= ps.ev.size()) return false;
+    *start = ps.ev[2 * ps.used];
+    *stop = ps.ev[2 * ps.used + 1];
+    ++ps.used;
+    return true;
+}
+
 extern "C" {
+
+int fp8mi_profile_begin(int max_launches)
+{
+    if (max_launches <= 0) return fail(FP8MI_E_SHAPE, "fp8mi_profile_begin: max_launches must be positive");
+    ProfileState &ps = g_prof;
+    if (ps.on) return fail(FP8MI_E_UNSUPPORTED, "fp8mi_profile_begin: a profile is already open on this thread");
+    while (ps.ev.size() < (size_t)max_launches * 2) {
+        hipEvent_t e;
+        hipError_t rc = hipEventCreate(&e);
+        if (rc != hipSuccess) return fail((int)rc, "hipEventCreate: %s", hipGetErrorString(rc));
+        ps.ev.push_back(e);
+    }
+    ps.used = 0;
+    ps.on = true;
+    return 0;
+}
+
+int fp8mi_profile_end(float *ms_out, int cap)
+{
+    ProfileState &ps = g_prof;
+    if (!ps.on) return fail(FP8MI_E_UNSUPPORTED, "fp8mi_profile_end: no profile open on this thread");
+    ps.on = false;
+    const int n = ps.used;
+    if (n > 0) {
+        hipError_t rc = hipEventSynchronize(ps.ev[2 * (n - 1) + 1]);
+        if (rc != hipSuccess) return fail((int)rc, "hipEventSynchronize: %s", hipGetErrorString(rc));
+    }
+    for (int i = 0; i < n && i < cap && ms_out; ++i) {
+        float ms = 0.0f;
+        hipError_t rc = hipEventElapsedTime(&ms, ps.ev[2 * i], ps.ev[2 * i + 1]);
+        if (rc != hipSuccess) return fail((int)rc, "hipEventElapsedTime: %s", hipGetErrorString(rc));
+        ms_out[i] = ms;
+    }
+    return n;
+}
 
 int fp8mi_version(void) { return FP8MI_VERSION; }
 

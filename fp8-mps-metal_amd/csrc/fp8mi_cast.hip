@@ -40,6 +40,13 @@ FP8MI_DEVICE void decode4_half(uint32_t w, f16x2 &lo, f16x2 &hi)
     hi = __builtin_bit_cast(f16x2, fp8x2_to_half2_bits(b)) * k256;
 }
 
+// one byte -> half, same bit trick (a true f16 multiply keeps the sign of -0.0)
+FP8MI_DEVICE _Float16 decode1_half(uint32_t b)
+{
+    const uint16_t hb = (uint16_t)fp8x2_to_half2_bits((b & 0xFFu) << 8);
+    return __builtin_bit_cast(_Float16, hb) * (_Float16)256.0f;
+}
+
 template <int OUT>
 struct OutVec;  // 16 output elements
 
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(kBlock) void dequant_kernel(const uint8_t *__restri
     if (blockIdx.x == 0) {
         int64_t i = (n16 << 4) + threadIdx.x;
         if (i < count) {
-            _Float16 v = (_Float16)decode_ref(in[i]);
+            _Float16 v = decode1_half(in[i]);
             if (has_scale) v = v * s;
             OutVec<OUT>::store1(out, i, v);
         }
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(kBlock) void dequant_scalar_kernel(const uint8_t *_
     _Float16 s = has_scale ? (_Float16)scale[0] : (_Float16)1.0f;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) {
-        _Float16 v = (_Float16)decode_ref(in[i]);
+        _Float16 v = decode1_half(in[i]);
         if (has_scale) v = v * s;
         OutVec<OUT>::store1(out, i, v);
     }
@@ -227,9 +234,11 @@ struct InVec<FP8MI_F16> {
             u32x4 v = __builtin_nontemporal_load(p + j);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                f16x2 h = __builtin_bit_cast(f16x2, v[q]);
-                f[8 * j + 2 * q] = (float)h[0];
-                f[8 * j + 2 * q + 1] = (float)h[1];
+                // NB: bit_cast straight from the vector element v[q] miscompiles
+                // (every q reads element 0, hipcc 7.2); go through a scalar.
+                const uint32_t w = v[q];
+                f[8 * j + 2 * q] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu));
+                f[8 * j + 2 * q + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
             }
         }
     }
@@ -371,8 +380,8 @@ int fp8mi_launch_dequant(const uint8_t *in, void *out, const float *scale, int64
     const int grid = grid_for(vec ? (count >> 4) : count);
 #define FP8MI_DQ(OUT)                                                                              \
     do {                                                                                           \
-        if (vec) hipLaunchKernelGGL(dequant_kernel<OUT>, dim3(grid), dim3(kBlock), 0, s, in, out, scale, count); \
-        else hipLaunchKernelGGL(dequant_scalar_kernel<OUT>, dim3(grid), dim3(kBlock), 0, s, in, out, scale, count); \
+        if (vec) FP8MI_LAUNCH(dequant_kernel<OUT>, dim3(grid), dim3(kBlock), s, in, out, scale, count); \
+        else FP8MI_LAUNCH(dequant_scalar_kernel<OUT>, dim3(grid), dim3(kBlock), s, in, out, scale, count); \
     } while (0)
     if (out_dtype == FP8MI_F16) FP8MI_DQ(FP8MI_F16);
     else if (out_dtype == FP8MI_F32) FP8MI_DQ(FP8MI_F32);
@@ -388,11 +397,11 @@ static int launch_encode_in(const void *in, uint8_t *out, const float *prescale,
     const bool vec = aligned16(in) && aligned16(out);
     const int grid = grid_for(vec ? (count >> 4) : count);
     if (mode == FP8MI_ENC_REFERENCE) {
-        if (vec) hipLaunchKernelGGL((encode_kernel<IN, FP8MI_ENC_REFERENCE>), dim3(grid), dim3(kBlock), 0, s, in, out, prescale, count);
-        else hipLaunchKernelGGL((encode_scalar_kernel<IN, FP8MI_ENC_REFERENCE>), dim3(grid), dim3(kBlock), 0, s, in, out, prescale, count);
+        if (vec) FP8MI_LAUNCH((encode_kernel<IN, FP8MI_ENC_REFERENCE>), dim3(grid), dim3(kBlock), s, in, out, prescale, count);
+        else FP8MI_LAUNCH((encode_scalar_kernel<IN, FP8MI_ENC_REFERENCE>), dim3(grid), dim3(kBlock), s, in, out, prescale, count);
     } else {
-        if (vec) hipLaunchKernelGGL((encode_kernel<IN, FP8MI_ENC_RNE>), dim3(grid), dim3(kBlock), 0, s, in, out, prescale, count);
-        else hipLaunchKernelGGL((encode_scalar_kernel<IN, FP8MI_ENC_RNE>), dim3(grid), dim3(kBlock), 0, s, in, out, prescale, count);
+        if (vec) FP8MI_LAUNCH((encode_kernel<IN, FP8MI_ENC_RNE>), dim3(grid), dim3(kBlock), s, in, out, prescale, count);
+        else FP8MI_LAUNCH((encode_scalar_kernel<IN, FP8MI_ENC_RNE>), dim3(grid), dim3(kBlock), s, in, out, prescale, count);
     }
     return (int)hipGetLastError();
 }
@@ -414,9 +423,9 @@ int fp8mi_launch_amax(const void *in, int in_dtype, float *out, int64_t count, h
     const int vec = aligned16(in) ? 1 : 0;
     const int grid = grid_for(vec ? ((count >> 4) > 0 ? (count >> 4) : 1) : count);
     uint32_t *ob = (uint32_t *)out;
-    if (in_dtype == FP8MI_F32) hipLaunchKernelGGL(amax_kernel<FP8MI_F32>, dim3(grid), dim3(kBlock), 0, s, in, ob, count, vec);
-    else if (in_dtype == FP8MI_F16) hipLaunchKernelGGL(amax_kernel<FP8MI_F16>, dim3(grid), dim3(kBlock), 0, s, in, ob, count, vec);
-    else hipLaunchKernelGGL(amax_kernel<FP8MI_BF16>, dim3(grid), dim3(kBlock), 0, s, in, ob, count, vec);
+    if (in_dtype == FP8MI_F32) FP8MI_LAUNCH(amax_kernel<FP8MI_F32>, dim3(grid), dim3(kBlock), s, in, ob, count, vec);
+    else if (in_dtype == FP8MI_F16) FP8MI_LAUNCH(amax_kernel<FP8MI_F16>, dim3(grid), dim3(kBlock), s, in, ob, count, vec);
+    else FP8MI_LAUNCH(amax_kernel<FP8MI_BF16>, dim3(grid), dim3(kBlock), s, in, ob, count, vec);
     return (int)hipGetLastError();
 }
 
@@ -425,7 +434,7 @@ int fp8mi_launch_quantize(const void *in, int in_dtype, uint8_t *out, float *sca
 {
     int rc = fp8mi_launch_amax(in, in_dtype, scales, count, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(quant_scale_kernel, dim3(1), dim3(1), 0, s, scales);
+    FP8MI_LAUNCH(quant_scale_kernel, dim3(1), dim3(1), s, scales);
     rc = (int)hipGetLastError();
     if (rc) return rc;
     return fp8mi_launch_encode(in, in_dtype, out, scales, count, mode, s);

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/fp8mi.h"
@@ -55,13 +56,18 @@ FP8MI_DEVICE bool has_nan4(uint32_t w)
 
 // one byte -> float, reference semantics (fp8_matmul.metal:19-40): used by the
 // slow paths only; the hot kernels decode with v_cvt_pk_f32_fp8 / MFMA.
+// Built from bits, with no float multiply on the signed value: hipcc fuses
+// `x * 2^k` followed by a conversion into v_fma_mix*(x, 2^k, +0), and
+// (-0 * c) + (+0) is +0 - the sign of 0x80 (-0.0, metal:39) would be lost.
 FP8MI_DEVICE float decode_ref(uint32_t b)
 {
-    if ((b & 0x7Fu) == 0x7Fu) return 0.0f;
-    // place sign|exp|mant into float bits with the exponent field low, then
-    // rescale by 2^120 (bias 127 -> 7); exact for normals and subnormals.
-    uint32_t bits = ((b & 0x80u) << 24) | ((b & 0x7Fu) << 20);
-    return __uint_as_float(bits) * 0x1p120f;
+    const uint32_t mag = b & 0x7Fu;
+    if (mag == 0x7Fu) return 0.0f;
+    const uint32_t sign = (b & 0x80u) << 24;
+    uint32_t bits;
+    if (mag >= 8u) bits = (mag << 20) + (120u << 23);           // normal: rebias 7 -> 127
+    else bits = __float_as_uint((float)mag * 0x1p-9f);           // subnormal: m * 2^-9 (>= 0, exact)
+    return __uint_as_float(bits | sign);
 }
 
 FP8MI_DEVICE float load_as_float(const void *p, int64_t i, int dtype)
@@ -96,6 +102,21 @@ FP8MI_DEVICE float wave_sum(float v)
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+
+// Per-dispatch timing hook (fp8mi_profile_begin / _end in the C ABI): while a
+// profile is open on the calling thread every kernel launch carries its own
+// start/stop event pair, filled from the dispatch packet's timestamps - the
+// same clock rocprofv3 --kernel-trace reads.  Outside a profile this is a
+// plain launch.
+bool fp8mi_next_profile_events(hipEvent_t *start, hipEvent_t *stop);
+#define FP8MI_LAUNCH(kernel, grid, block, stream, ...)                                         \
+    do {                                                                                       \
+        hipEvent_t e0_, e1_;                                                                   \
+        if (fp8mi_next_profile_events(&e0_, &e1_))                                             \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, e0_, e1_, 0, __VA_ARGS__);   \
+        else                                                                                   \
+            hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                   \
+    } while (0)
 
 // launchers implemented in the .hip files (host side, internal linkage by name)
 int fp8mi_launch_gemv(const MMParams &p, hipStream_t s);

@@ -275,7 +275,7 @@ int launch(const MMParams &p, hipStream_t s)
     if (tm * tn > 0x7FFFFFFF) return FP8MI_E_UNSUPPORTED;
     const int esz = p.out_dtype == FP8MI_F32 ? 4 : 2;
     const int vec = ((p.ldc % 4) == 0 && (((uintptr_t)p.C) % (4 * esz)) == 0) ? 1 : 0;
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), dim3((unsigned)(tm * tn)), dim3(C::kThreads), 0, s, p, (int)tm,
+    FP8MI_LAUNCH((gemm_kernel<BM, BN, WM, WN>), dim3((unsigned)(tm * tn)), dim3(C::kThreads), s, p, (int)tm,
                        vec);
     return (int)hipGetLastError();
 }

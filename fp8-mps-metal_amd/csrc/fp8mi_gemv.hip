@@ -160,7 +160,7 @@ template <int STEPS, int RB>
 int launch(const MMParams &p, hipStream_t s)
 {
     const int64_t grid = (p.N + RB - 1) / RB;
-    hipLaunchKernelGGL((gemv_kernel<STEPS, RB>), dim3((unsigned)grid), dim3(kThreads), 0, s, p);
+    FP8MI_LAUNCH((gemv_kernel<STEPS, RB>), dim3((unsigned)grid), dim3(kThreads), s, p);
     return (int)hipGetLastError();
 }
 

@@ -49,6 +49,6 @@ int fp8mi_launch_generic(const MMParams &p, hipStream_t s)
     const int64_t gy = p.M < 65535 ? p.M : 65535;
     const int64_t gz = (p.M + 65534) / 65535;
     if (gx > 0x7FFFFFFF || gz > 65535) return FP8MI_E_UNSUPPORTED;
-    hipLaunchKernelGGL(generic_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)gz), dim3(kWavesPerBlock * 64), 0, s, p);
+    FP8MI_LAUNCH(generic_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)gz), dim3(kWavesPerBlock * 64), s, p);
     return (int)hipGetLastError();
 }

@@ -54,6 +54,8 @@ SIGNATURES = {
     "fp8mi_amax": (_int, [_vp, _int, _vp, _i64, _vp]),
     "fp8mi_quantize": (_int, [_vp, _int, _vp, _vp, _i64, _int, _vp]),
     "fp8mi_device_info": (_int, [_int, ctypes.POINTER(DeviceInfo)]),
+    "fp8mi_profile_begin": (_int, [_int]),
+    "fp8mi_profile_end": (_int, [ctypes.POINTER(ctypes.c_float), _int]),
     "fp8mi_version": (_int, []),
     "fp8mi_last_error": (ctypes.c_char_p, []),
 }
@@ -97,6 +99,28 @@ def check(rc: int, what: str):
     if rc != 0:
         msg = load().fp8mi_last_error()
         raise Fp8miError(f"{what} failed (code {rc}): {msg.decode(errors='replace') if msg else ''}")
+
+
+class kernel_timer:
+    """Context manager around fp8mi_profile_begin/_end: collects the pure
+    device duration (ms) of every kernel the library launches from this
+    thread inside the block, in launch order, into `.ms`."""
+
+    def __init__(self, max_launches: int):
+        self.n = int(max_launches)
+        self.ms = []
+
+    def __enter__(self):
+        check(load().fp8mi_profile_begin(self.n), "fp8mi_profile_begin")
+        return self
+
+    def __exit__(self, *exc):
+        buf = (ctypes.c_float * self.n)()
+        got = load().fp8mi_profile_end(buf, self.n)
+        if got < 0:
+            check(got, "fp8mi_profile_end")
+        self.ms = [float(buf[i]) for i in range(min(got, self.n))]
+        return False
 
 
 def device_info(device: int = 0) -> dict:

@@ -168,6 +168,21 @@ typedef struct fp8mi_device_info {
 /* Host-side query of HIP device `device` (for the roofline harness). */
 int fp8mi_device_info(int device, fp8mi_device_info_t *out);
 
+/*
+ * Per-dispatch kernel timing for the measurement harness (bench.py).  Between
+ * fp8mi_profile_begin(n) and fp8mi_profile_end() every kernel this library
+ * launches FROM THE CALLING THREAD carries its own start/stop HIP event pair
+ * filled from the dispatch packet's timestamps (hipExtLaunchKernelGGL) - the
+ * clock rocprofv3 --kernel-trace reads - up to n launches.  _end() waits for
+ * the last profiled launch, writes up to `cap` durations (milliseconds, launch
+ * order) to the HOST array ms_out and returns how many launches were timed (or
+ * a negative error).  Not for use inside graph capture.  No reference
+ * counterpart: the reference times with time.perf_counter() around
+ * torch.mps.synchronize() (test_fp8_metal.py:248-255).
+ */
+int fp8mi_profile_begin(int max_launches);
+int fp8mi_profile_end(float *ms_out, int cap);
+
 int fp8mi_version(void);
 const char *fp8mi_last_error(void);
 

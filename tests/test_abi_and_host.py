@@ -1,0 +1,188 @@
+"""CPU: the C-ABI library loads and exports every symbol include/fp8mi.h
+declares (no compute without a GPU), and the host-side routing logic of the
+monkey-patch behaves like the reference's (fp8_mps_patch.py)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+from conftest import PKG, ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    so = os.path.join(PKG, "libfp8mi.so")
+    srcs = [os.path.join(PKG, "csrc", f) for f in os.listdir(os.path.join(PKG, "csrc")) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(ROOT, "include", "fp8mi.h"))
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["make", "-C", PKG, "-s", "-j4"])
+    import fp8_mi355x_lib
+    return fp8_mi355x_lib.load()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "fp8mi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fp8mi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    import fp8_mi355x_lib
+    names = _declared_symbols()
+    assert {"fp8mi_scaled_mm", "fp8mi_scaled_mm_ex", "fp8mi_dequant", "fp8mi_encode", "fp8mi_amax",
+            "fp8mi_quantize", "fp8mi_device_info", "fp8mi_version", "fp8mi_last_error",
+            "fp8mi_profile_begin", "fp8mi_profile_end"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/fp8mi.h but not exported"
+        assert n in fp8_mi355x_lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert set(fp8_mi355x_lib.SIGNATURES) == set(names)
+
+
+def test_version_and_argument_errors_without_gpu(lib):
+    assert lib.fp8mi_version() == 0x000100
+    # argument validation happens before any HIP call, so it is testable here
+    rc = lib.fp8mi_scaled_mm(None, None, None, None, None, None, None, 4, 4, 4, 4, 4, 4, 0, 0, 0, 0, 0, None)
+    assert rc == -1 and b"NULL" in lib.fp8mi_last_error()
+    rc = lib.fp8mi_scaled_mm(None, None, None, None, None, None, None, -1, 4, 4, 4, 4, 4, 0, 0, 0, 0, 0, None)
+    assert rc == -2
+    one = ctypes.c_void_p(16)
+    rc = lib.fp8mi_scaled_mm(one, one, one, one, one, None, None, 4, 4, 8, 4, 8, 4, 0, 0, 0, 0, 0, None)
+    assert rc == -2 and b"leading dimension" in lib.fp8mi_last_error()
+    rc = lib.fp8mi_scaled_mm(one, one, one, one, one, None, None, 4, 4, 8, 8, 8, 4, 0, 0, 7, 0, 0, None)
+    assert rc == -3
+    assert lib.fp8mi_dequant(None, None, None, 0, 0, None) == 0      # empty is a no-op
+    assert lib.fp8mi_dequant(None, None, None, 5, 0, None) == -1
+    assert lib.fp8mi_encode(one, 9, one, None, 5, 0, None) == -3
+    assert lib.fp8mi_scaled_mm(None, None, None, None, None, None, None, 0, 4, 4, 4, 4, 4, 0, 0, 0, 0, 0, None) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    import fp8_mi355x_lib
+    monkeypatch.setattr(fp8_mi355x_lib, "_lib", None)
+    monkeypatch.setattr(fp8_mi355x_lib, "LIB_PATH", "/nonexistent/libfp8mi.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fp8_mi355x_lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    for root, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(root, f)).read()
+                assert "fp8_oracle" not in text and "oracle/" not in text, f
+
+
+# ---- monkey-patch surface (test_fp8_metal.py:318-349, test_mps_limits_patch.py:128-153) ----
+
+def test_patch_module_structure():
+    import fp8_mps_patch as p
+    for name in ("install", "uninstall", "is_installed", "patch_vae_decode_for_mps_limits",
+                 "_metal_scaled_mm", "_metal_tensor_to", "_metal_tensor_copy"):
+        assert callable(getattr(p, name)), name
+
+
+def test_install_uninstall_restores_identical_objects():
+    import fp8_mps_patch as p
+    o_mm, o_to, o_cp = torch._scaled_mm, torch.Tensor.to, torch.Tensor.copy_
+    assert not p.is_installed()
+    p.install()
+    try:
+        assert p.is_installed()
+        assert torch._scaled_mm is p._metal_scaled_mm
+        assert torch.Tensor.to is p._metal_tensor_to and torch.Tensor.copy_ is p._metal_tensor_copy
+        assert p._original_scaled_mm is o_mm and p._original_tensor_to is o_to and p._original_tensor_copy is o_cp
+        p.install()  # idempotent
+        assert p._original_scaled_mm is o_mm
+    finally:
+        p.uninstall()
+    assert not p.is_installed()
+    assert torch._scaled_mm is o_mm and torch.Tensor.to is o_to and torch.Tensor.copy_ is o_cp
+    assert p._original_scaled_mm is None and p._original_tensor_to is None and p._original_tensor_copy is None
+    p.uninstall()  # no-op
+
+
+def test_cpu_calls_pass_through_unchanged(patch):
+    """With the patch installed, CPU tensors behave exactly as unpatched."""
+    x = torch.randn(4, 8)
+    assert x.to(torch.float16).dtype == torch.float16
+    assert x.to("cpu", torch.float64).dtype == torch.float64
+    ref = patch._original_tensor_to(x, torch.float8_e4m3fn)
+    got = x.to(torch.float8_e4m3fn)
+    assert got.dtype == torch.float8_e4m3fn and torch.equal(got.view(torch.uint8), ref.view(torch.uint8))
+    assert torch.equal(got.to(torch.float32), patch._original_tensor_to(ref, torch.float32))
+    y = torch.empty(4, 8, dtype=torch.float8_e4m3fn)
+    assert y.copy_(x) is y and torch.equal(y.view(torch.uint8), ref.view(torch.uint8))
+    z = torch.zeros(4, 8)
+    z.copy_(x)
+    assert torch.equal(z, x)
+    z.copy_(torch.tensor(3.0))
+    assert torch.all(z == 3)
+    assert x.to(x.to(torch.float16)).dtype == torch.float16  # to(other) overload
+
+
+def test_to_argument_parsing():
+    import fp8_mps_patch as p
+    f8 = torch.float8_e4m3fn
+    assert p._parse_to_args((f8,), {}) == (f8, None, {})
+    assert p._parse_to_args(("cuda",), {}) == (None, "cuda", {})
+    assert p._parse_to_args(("cuda:1", f8), {}) == (f8, "cuda:1", {})
+    assert p._parse_to_args((torch.device("cuda", 0), f8, True), {}) == (f8, torch.device("cuda", 0), {"non_blocking": True})
+    assert p._parse_to_args((), {"dtype": f8, "device": "cuda", "copy": True}) == (f8, "cuda", {"copy": True})
+    d, dev, extra = p._parse_to_args((), {"dtype": torch.float16, "memory_format": torch.contiguous_format})
+    assert d == torch.float16 and dev is None and extra == {"memory_format": torch.contiguous_format}
+    t = torch.zeros(1, dtype=torch.float16)
+    assert p._parse_to_args((t,), {})[:2] == (torch.float16, t.device)
+
+
+def test_to_routing_table():
+    """The scenario routing of _metal_tensor_to (fp8_mps_patch.py:160-226),
+    with "cuda" in the role of "mps"."""
+    import fp8_mps_patch as p
+    f8, f5 = torch.float8_e4m3fn, torch.float8_e5m2
+    S = p._to_scenario
+    # S1: fp8 elsewhere -> device: raw byte transfer
+    assert S(f8, False, None, "cuda") == "bytes_to_device"
+    assert S(f8, False, f8, "cuda:0") == "bytes_to_device"
+    assert S(f5, False, None, "cuda") == "bytes_to_device"
+    assert S(f8, False, torch.float16, "cuda") == "bytes_to_device"   # then dequantised
+    assert S(f8, False, f5, "cuda") == "original"
+    # S2: float -> e4m3 on device: encode kernel
+    assert S(torch.float32, True, f8, None) == "encode"
+    assert S(torch.bfloat16, False, f8, "cuda") == "encode"
+    assert S(torch.float32, False, f8, None) == "original"             # CPU stays CPU
+    assert S(torch.float32, True, f5, None) == "original"              # e5m2 is torch's business
+    # S3: e4m3 on device
+    assert S(f8, True, None, None) == "same" and S(f8, True, f8, "cuda") == "same"
+    assert S(f8, True, torch.float16, None) == "dequant" and S(f8, True, torch.float32, "cuda") == "dequant"
+    assert S(f8, True, f5, None) == "original"
+    assert S(f8, True, torch.int32, None) == "original"
+    assert S(f8, True, None, "cpu") == "original" and S(f5, True, torch.float16, None) == "original"
+    # nothing fp8: always torch
+    assert S(torch.float32, True, torch.float16, None) == "original"
+    assert S(torch.float32, False, None, "cuda") == "original"
+
+
+def test_copy_routing_table():
+    import fp8_mps_patch as p
+    f8, f5 = torch.float8_e4m3fn, torch.float8_e5m2
+    C = p._copy_scenario
+    assert C(f8, True, f8) == "bytes" and C(f5, True, f5) == "bytes"
+    assert C(f8, True, torch.float32) == "encode" and C(f8, True, torch.bfloat16) == "encode"
+    assert C(f8, True, f5) == "original" and C(f5, True, torch.float32) == "original"
+    assert C(torch.float32, True, f8) == "original"                    # fp8_mps_patch.py:296-299
+    assert C(f8, False, torch.float32) == "original" and C(f8, False, f8) == "original"
+
+
+def test_scaled_mm_cpu_passthrough_and_positional_scales(patch):
+    a = torch.randn(16, 32).to(torch.float8_e4m3fn)
+    b = torch.randn(16, 32).to(torch.float8_e4m3fn).t()
+    one = torch.ones(1)
+    try:
+        ref = patch._original_scaled_mm(a, b, scale_a=one, scale_b=one, out_dtype=torch.float32)
+    except Exception as e:
+        pytest.skip(f"torch-CPU _scaled_mm unavailable: {e}")
+    assert torch.equal(torch._scaled_mm(a, b, scale_a=one, scale_b=one, out_dtype=torch.float32), ref)
+    assert torch.equal(torch._scaled_mm(a, b, one, one, out_dtype=torch.float32), ref)

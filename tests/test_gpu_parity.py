@@ -1,0 +1,491 @@
+"""GPU (MI355X): parity of the HIP path with the oracle and the golden vectors.
+
+Every call goes through the product's op layer -> ctypes -> libfp8mi.so (the
+C-ABI); the oracle is only the checker.  Bars:
+  * casts: bit-exact (decode of all 256 patterns, every golden encode vector);
+  * matmul: float32 accumulation, so |gpu - exact| <= MM_TOL * sum_k|a||b||sa||sb|
+    against the float64 oracle (exact products, see oracle/fp8_oracle.py), and
+    the reference's own accuracy gate (rel-RMSE vs fp32 matmul, ~4 %).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# VALU paths (GEMV, generic): true float32 accumulation.  Error allowed relative
+# to sum|a||b|: fp32 eps is 6e-8; a K = 16384 dot product accumulated in fp32 in
+# any order stays well inside.
+MM_TOL = 4e-6
+# MFMA paths: the gfx950 fp8 matrix core does NOT accumulate like fp32.  Measured
+# (tools/mfma_probe.hip, profiles/mfma_numerics_r01.txt; identical for the legacy
+# v_mfma_f32_16x16x32_fp8_fp8 and the scaled v_mfma_scale_f32_16x16x128_f8f6f4):
+# inside each group of 8 products the addends are aligned to the group's largest
+# and bits more than ~13 binary places below it are truncated.  Worst case
+# |err| <= 7 * 2^-13 * sum|a||b| (~8.5e-4); on random bytes the observed maximum is
+# ~1e-4 and operands within a 2^12 product range are summed exactly.
+MFMA_TOL = 1.0e-3       # hard bound, any input
+MFMA_RMS_TOL = 1.0e-4   # rms(err) / rms(sum|a||b|), random inputs
+REL_RMSE_GATE = 0.045  # reference reports 4.0 % (README.md:86), gates at 15 %
+
+import fp8_mi355x_lib as L  # noqa: E402
+
+
+def dev(x, cuda, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(cuda)
+
+
+def clean_bytes(rng, shape):
+    b = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    b[(b & 0x7F) == 0x7F] ^= 0x01  # 0x7F -> 0x7E, 0xFF -> 0xFE
+    return b
+
+
+def uses_mfma(kernel, M, K):
+    if kernel in (L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256):
+        return True
+    return kernel == L.KERNEL_AUTO and M > 1 and K % 16 == 0 and K > 0
+
+
+def check_mm(oracle, native, cuda, A, B, sa, sb, *, kernel=L.KERNEL_AUTO, bias=None, scale_result=None,
+             out_dtype=None, nan_mode=None, tol=None):
+    mfma = uses_mfma(kernel, A.shape[0], A.shape[1])
+    if tol is None:
+        tol = MFMA_TOL if mfma else MM_TOL
+    kw = {}
+    if bias is not None:
+        kw["bias"] = dev(bias, cuda)
+    if scale_result is not None:
+        kw["scale_result"] = dev(np.array([scale_result], np.float32), cuda)
+    got = native.fp8_scaled_mm(dev(A, cuda), dev(B, cuda), dev(np.asarray(sa, np.float32), cuda),
+                               dev(np.asarray(sb, np.float32), cuda), out_dtype=out_dtype, kernel=kernel,
+                               nan_mode=nan_mode, **kw)
+    torch.cuda.synchronize()
+    assert got.shape == (A.shape[0], B.shape[0])
+    assert got.dtype == (out_dtype or torch.float32)
+    exact = oracle.scaled_mm(A, B, sa, sb, accumulate="f64")
+    bound = oracle.abs_dot_bound(A, B, sa, sb)
+    if bias is not None:
+        exact = exact + np.asarray(bias, np.float64)[None, :]
+        bound = bound + np.abs(np.asarray(bias, np.float64))[None, :]
+    if scale_result is not None:
+        exact = exact * scale_result
+        bound = bound * abs(scale_result)
+    g = got.float().cpu().numpy().astype(np.float64)
+    if out_dtype in (torch.bfloat16, torch.float16):
+        # one extra rounding to the 8- / 11-bit significand
+        eps = 2.0 ** -8 if out_dtype == torch.bfloat16 else 2.0 ** -11
+        assert np.all(np.abs(g - exact) <= tol * bound + eps * np.abs(exact) + 1e-30)
+    else:
+        ratio = np.max(np.abs(g - exact) / (bound + 1e-300))
+        assert np.all(np.abs(g - exact) <= tol * bound + 1e-30), f"max err/bound = {ratio:.3e}"
+        if mfma and tol == MFMA_TOL and g.size >= 64:
+            rms = np.sqrt(np.mean((g - exact) ** 2)) / (np.sqrt(np.mean(bound ** 2)) + 1e-300)
+            assert rms <= MFMA_RMS_TOL, f"rms err / rms bound = {rms:.3e}"
+    return got
+
+
+# ---------------------------------------------------------------------------
+# casts
+# ---------------------------------------------------------------------------
+
+def test_decode_all_256_patterns_bit_exact(native, cuda, golden_dir):
+    """The 256-pattern decode gate (test_fp8_metal.py:53-94, BASELINE configs[4])."""
+    g = json.load(open(os.path.join(golden_dir, "decode_256.json")))
+    b = torch.arange(256, dtype=torch.uint8, device=cuda)
+    h = native.fp8_dequantize(b, torch.tensor([1.0]))
+    assert h.dtype == torch.float16
+    assert np.array_equal(h.cpu().view(torch.int16).numpy().view(np.uint16), np.array(g["f16_bits"], np.uint16))
+    h2 = native.fp8_dequantize(b, None)
+    assert torch.equal(h2.view(torch.int16), h.view(torch.int16))
+    f = native.fp8_dequantize(b, None, out_dtype=torch.float32)
+    assert np.array_equal(f.cpu().numpy().view(np.uint32), np.array(g["f32_bits"], np.uint32))
+    bf = native.fp8_dequantize(b, None, out_dtype=torch.bfloat16)
+    assert torch.equal(bf.float().cpu(), f.cpu())  # every e4m3 value is exact in bf16 (8-bit significand)
+
+
+@pytest.mark.parametrize("count,offset", [(1, 0), (15, 0), (16, 0), (17, 0), (1000, 0), (4099, 0), (1 << 20, 0),
+                                          (1000, 1), (4099, 3), (77, 16)])
+def test_dequant_sizes_alignment_and_scale(native, cuda, oracle, count, offset):
+    rng = np.random.default_rng(count + offset)
+    raw = rng.integers(0, 256, size=count + offset, dtype=np.uint8)
+    t = dev(raw, cuda)[offset:]
+    for scale in (None, 0.5, 0.0137, 300.0):
+        s = None if scale is None else torch.tensor([scale])
+        got = native.fp8_dequantize(t, s)
+        exp = oracle.dequantize_f16(raw[offset:], 1.0 if scale is None else scale)
+        assert np.array_equal(got.cpu().view(torch.int16).numpy().view(np.uint16), exp.view(np.uint16)), scale
+    # float32 / bfloat16 outputs = conversions of that half value (fp8_mps_patch.py:219-221)
+    got32 = native.fp8_dequantize(t, torch.tensor([0.0137]), out_dtype=torch.float32)
+    exp16 = torch.from_numpy(oracle.dequantize_f16(raw[offset:], 0.0137))
+    assert torch.equal(got32.cpu(), exp16.float())
+    gotbf = native.fp8_dequantize(t, torch.tensor([0.0137]), out_dtype=torch.bfloat16)
+    assert torch.equal(gotbf.cpu(), exp16.float().to(torch.bfloat16))
+
+
+def test_dequant_shapes_and_empty(native, cuda):
+    e = native.fp8_dequantize(torch.empty(0, dtype=torch.uint8, device=cuda), None)
+    assert e.shape == (0,) and e.dtype == torch.float16
+    x = torch.randint(0, 256, (3, 5, 7), dtype=torch.uint8, device=cuda)
+    assert native.fp8_dequantize(x, None).shape == (3, 5, 7)
+    assert native.fp8_dequantize(x.cpu(), None).device.type == "cuda"  # moved, as the reference moves to mps
+
+
+def test_encode_golden_vectors_byte_exact(native, cuda, golden_dir):
+    d = np.load(os.path.join(golden_dir, "encode_vectors.npz"))
+    x = d["in_bits"].view(np.float32)
+    got = native.fp8_encode(dev(x, cuda))
+    assert got.dtype == torch.uint8
+    bad = np.nonzero(got.cpu().numpy() != d["out"])[0]
+    assert bad.size == 0, [(float(x[i]), hex(int(got[i])), hex(int(d["out"][i]))) for i in bad[:5]]
+
+
+def test_encode_known_answers_and_value_lists(native, cuda, golden_dir):
+    kat = json.load(open(os.path.join(golden_dir, "kat.json")))
+    xs = torch.tensor([p[0] for p in kat["encode_known_answers"]], dtype=torch.float32, device=cuda)
+    assert native.fp8_encode(xs).cpu().tolist() == [p[1] for p in kat["encode_known_answers"]]
+    for name, pairs in kat["value_lists"].items():
+        xs = torch.tensor([p[0] for p in pairs], dtype=torch.float32, device=cuda)
+        assert native.fp8_encode(xs).cpu().tolist() == [p[1] for p in pairs], name
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_encode_half_inputs(native, cuda, oracle, dtype):
+    rng = np.random.default_rng(7)
+    x = torch.from_numpy((rng.standard_normal(100003) * 16).astype(np.float32)).to(dtype)
+    special = torch.tensor([0.0, -0.0, 448.0, 449.0, 1e4, -1e4, 6e-5, 2.0 ** -9, 2.0 ** -10, 0.0019, float("inf")]).to(dtype)
+    x = torch.cat([x, special])
+    got = native.fp8_encode(x.to(cuda)).cpu().numpy()
+    assert np.array_equal(got, oracle.encode(x.float().numpy()))
+
+
+@pytest.mark.parametrize("count,offset", [(1, 0), (15, 0), (17, 0), (4099, 0), (1000, 1), (4099, 3)])
+def test_encode_sizes_and_alignment(native, cuda, oracle, count, offset):
+    rng = np.random.default_rng(100 + count + offset)
+    raw = (rng.standard_normal(count + offset) * 30).astype(np.float32)
+    got = native.fp8_encode(dev(raw, cuda)[offset:])
+    assert np.array_equal(got.cpu().numpy(), oracle.encode(raw[offset:]))
+
+
+def test_encode_rne_mode_equals_torch_cpu(native, cuda, golden_dir):
+    d = np.load(os.path.join(golden_dir, "encode_vectors.npz"))
+    x = torch.from_numpy(d["in_bits"].view(np.float32).copy())
+    x = torch.cat([x, torch.tensor([float("nan"), -float("nan")])])
+    exp = x.to(torch.float8_e4m3fn).view(torch.uint8)
+    got = native.fp8_encode(x.to(cuda), encode_mode=L.ENC_RNE).cpu()
+    assert torch.equal(got[:-2], exp[:-2])
+    assert (got[-2:] & 0x7F).tolist() == [0x7F, 0x7F]
+
+
+def test_encode_other_dtypes_and_shapes(native, cuda, oracle):
+    assert native.fp8_encode(torch.empty(0, device=cuda)).shape == (0,)
+    i = torch.arange(-20, 20, dtype=torch.int64, device=cuda).reshape(4, 10)
+    got = native.fp8_encode(i)
+    assert got.shape == (4, 10)
+    assert np.array_equal(got.cpu().numpy().ravel(), oracle.encode(np.arange(-20, 20, dtype=np.float32)))
+    d = torch.tensor([3.14], dtype=torch.float64)
+    assert native.fp8_encode(d).cpu().tolist() == oracle.encode(np.array([3.14], np.float32)).tolist()
+
+
+def test_amax_and_quantize(native, cuda, oracle):
+    rng = np.random.default_rng(11)
+    for n in (1, 7, 1000, 262147):
+        x = (rng.standard_normal(n) * 3).astype(np.float32)
+        assert float(native.fp8_amax(dev(x, cuda)).cpu()) == float(np.max(np.abs(x)))
+        q, inv = native.fp8_quantize(dev(x, cuda))
+        eq, einv = oracle.quantize(x)
+        assert inv.shape == (1,) and inv.dtype == torch.float32
+        assert float(inv.cpu()) == float(einv)
+        assert np.array_equal(q.cpu().numpy(), eq)
+    # bf16 source, zero input, quantize -> dequantize gate of test_fp8_metal.py:167-188
+    xb = torch.from_numpy((rng.standard_normal(4099) * 3).astype(np.float32)).to(torch.bfloat16)
+    q, inv = native.fp8_quantize(xb.to(cuda))
+    eq, einv = oracle.quantize(xb.float().numpy())
+    assert np.array_equal(q.cpu().numpy(), eq) and float(inv.cpu()) == float(einv)
+    q0, inv0 = native.fp8_quantize(torch.zeros(33, device=cuda))
+    assert float(inv0.cpu()) == 1.0 and not q0.any()
+    x = torch.tensor([0.0, 1.0, -1.0, 0.5, -0.5, 100.0, -100.0, 448.0], device=cuda)
+    q, inv = native.fp8_quantize(x)
+    back = native.fp8_dequantize(q, inv).float()
+    assert float((back - x).abs().max()) < 50
+
+
+def test_cast_roundtrip_property_large(native, cuda, oracle):
+    """2^27 elements: enc(dec(enc(x))) == enc(x) everywhere (idempotence, modulo -0), and
+    a 2^20-element sample equals the oracle byte for byte."""
+    n = 1 << 27
+    g = torch.Generator(device=cuda).manual_seed(1234)
+    x = torch.randn(n, device=cuda, generator=g) * 16
+    q = native.fp8_encode(x)
+    h = native.fp8_dequantize(q, None)
+    q2 = native.fp8_encode(h)
+    # 0x80 (what small negatives flush to) decodes to -0.0, which re-encodes to 0x00:
+    # the reference's own round-trip exception (test_fp8_correctness.py:118-131)
+    assert torch.equal(torch.where(q == 0x80, torch.zeros_like(q), q), q2)
+    assert bool((q == 0x80).any())
+    idx = torch.randint(0, n, (1 << 20,), device=cuda, generator=g)
+    assert np.array_equal(q[idx].cpu().numpy(), oracle.encode(x[idx].cpu().numpy()))
+    assert np.array_equal(h[idx].cpu().view(torch.int16).numpy().view(np.uint16),
+                          oracle.dequantize_f16(q[idx].cpu().numpy()).view(np.uint16))
+    assert not bool(((q & 0x7F) == 0x7F).any())  # the reference encoder never emits a NaN pattern
+
+
+# ---------------------------------------------------------------------------
+# scaled matmul: golden cases through every kernel that can run them
+# ---------------------------------------------------------------------------
+
+def _golden_cases(golden_dir):
+    d = np.load(os.path.join(golden_dir, "matmul_cases.npz"))
+    for ci in range(int(d["n_cases"])):
+        yield ci, d[f"c{ci}_A"], d[f"c{ci}_B"], d
+
+
+def _kernels_for(M, K):
+    ks = [L.KERNEL_AUTO, L.KERNEL_GENERIC]
+    if K % 16 == 0:
+        ks += [L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256]
+        if M == 1:
+            ks.append(L.KERNEL_GEMV)
+    return ks
+
+
+def test_golden_matmul_cases_all_kernels(native, cuda, oracle, golden_dir):
+    """Seeded byte matrices INCLUDING NaN patterns (0x7F/0xFF decode to 0,
+    fp8_matmul.metal:21), per-tensor and per-row scales."""
+    for ci, A, B, d in _golden_cases(golden_dir):
+        M, K = A.shape
+        for kernel in _kernels_for(M, K):
+            tol = MFMA_TOL if uses_mfma(kernel, M, K) else MM_TOL
+            got = check_mm(oracle, native, cuda, A, B, d[f"c{ci}_sa1"], d[f"c{ci}_sb1"], kernel=kernel)
+            bound = oracle.abs_dot_bound(A, B, d[f"c{ci}_sa1"], d[f"c{ci}_sb1"])
+            assert np.all(np.abs(got.cpu().numpy() - d[f"c{ci}_out_tensor"]) <= tol * bound + 1e-30), (ci, kernel)
+            got = check_mm(oracle, native, cuda, A, B, d[f"c{ci}_saM"], d[f"c{ci}_sbN"], kernel=kernel)
+            bound = oracle.abs_dot_bound(A, B, d[f"c{ci}_saM"], d[f"c{ci}_sbN"])
+            assert np.all(np.abs(got.cpu().numpy() - d[f"c{ci}_out_row"]) <= tol * bound + 1e-30), (ci, kernel)
+
+
+def test_nan_modes(native, cuda, oracle):
+    rng = np.random.default_rng(21)
+    A = clean_bytes(rng, (32, 256))
+    B = clean_bytes(rng, (48, 256))
+    A[3, 17] = 0x7F
+    B[5, 100] = 0xFF
+    for kernel in (L.KERNEL_GEMM_128, L.KERNEL_GENERIC):
+        check_mm(oracle, native, cuda, A, B, [1.0], [1.0], kernel=kernel)  # reference mode: NaN byte = 0
+        got = native.fp8_scaled_mm(dev(A, cuda), dev(B, cuda), torch.ones(1), torch.ones(1), kernel=kernel,
+                                   nan_mode=L.NAN_PROPAGATE).cpu().numpy()
+        nan = np.isnan(got)
+        assert nan[3, :].all() and nan[:, 5].all() and nan.sum() == 48 + 32 - 1  # OCP: row 3 and column 5 poisoned
+    x = clean_bytes(rng, (1, 2048))
+    W = clean_bytes(rng, (64, 2048))
+    W[7, 5] = 0x7F
+    W[9, 2047] = 0xFF
+    x[0, 33] = 0xFF
+    check_mm(oracle, native, cuda, x, W, [0.5], [0.25], kernel=L.KERNEL_GEMV)
+    got = native.fp8_scaled_mm(dev(x, cuda), dev(W, cuda), torch.ones(1), torch.ones(1), kernel=L.KERNEL_GEMV,
+                               nan_mode=L.NAN_PROPAGATE).cpu().numpy()
+    assert np.isnan(got).all()  # a NaN in x poisons every output
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 16, 1), (1, 1040, 33), (1, 4096, 4096), (1, 14336, 4096), (1, 14352, 100),
+                                   (1, 20480, 72), (1, 1024, 8), (1, 2064, 17)])
+def test_gemv_shapes(native, cuda, oracle, M, K, N):
+    """Vec-mat path (fp8_matmul.metal:155-210): BASELINE configs[0] (K=N=4096) and
+    configs[1] (K=14336, N=4096) plus ragged K / N."""
+    rng = np.random.default_rng(K + N)
+    x = clean_bytes(rng, (1, K))
+    W = clean_bytes(rng, (N, K))
+    check_mm(oracle, native, cuda, x, W, [0.01], [0.01], kernel=L.KERNEL_GEMV)
+    sw = rng.uniform(0.005, 0.02, size=N).astype(np.float32)
+    check_mm(oracle, native, cuda, x, W, [0.013], sw, kernel=L.KERNEL_GEMV)
+    check_mm(oracle, native, cuda, x, W, [0.013], sw)  # auto dispatch picks the same path
+
+
+@pytest.mark.parametrize("kernel", [L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256])
+@pytest.mark.parametrize("M,K,N", [(1, 128, 1), (5, 16, 3), (128, 128, 128), (130, 272, 70), (300, 1040, 200),
+                                   (256, 512, 256), (257, 384, 513), (64, 4096, 96)])
+def test_gemm_tile_kernels_ragged(native, cuda, oracle, kernel, M, K, N):
+    """MFMA tile kernels on full and ragged tiles, K tails (K % 128 != 0) included."""
+    rng = np.random.default_rng(M * 7 + K * 3 + N)
+    A = clean_bytes(rng, (M, K))
+    B = clean_bytes(rng, (N, K))
+    sa = rng.uniform(0.005, 0.02, size=M).astype(np.float32)
+    sb = rng.uniform(0.005, 0.02, size=N).astype(np.float32)
+    check_mm(oracle, native, cuda, A, B, sa, sb, kernel=kernel)
+    check_mm(oracle, native, cuda, A, B, [0.01], sb, kernel=kernel)  # mixed per-tensor / per-row broadcasts
+
+
+def test_gemm_mfma_operand_map_asymmetric(native, cuda, oracle):
+    """A = 'identity-like' selector with an ASYMMETRIC B: catches a swapped
+    row/column map or a k-permutation mismatch between the two MFMA operands."""
+    K = 256
+    A = np.zeros((128, K), np.uint8)
+    for m in range(128):
+        A[m, (m * 5 + 3) % K] = 0x38  # 1.0 at a row-dependent k
+    rng = np.random.default_rng(3)
+    B = clean_bytes(rng, (128, K))
+    got = check_mm(oracle, native, cuda, A, B, [1.0], [1.0], kernel=L.KERNEL_GEMM_128, tol=0.0)
+    exp = oracle.decode(B)[:, [(m * 5 + 3) % K for m in range(128)]].T
+    assert np.array_equal(got.cpu().numpy(), exp)
+
+
+@pytest.mark.parametrize("kernel", [L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256])
+def test_gemm_fp32_exact_on_narrow_range(native, cuda, oracle, kernel):
+    """Operands with |x| in [0.25, 4): all products lie within 2^8 of each other,
+    above the matrix core's alignment cut-off, so the MFMA kernels must agree
+    with the oracle to float32 rounding - a software bug cannot hide behind the
+    hardware tolerance."""
+    rng = np.random.default_rng(77)
+    M, K, N = 200, 1024, 328
+    A = (0x28 + rng.integers(0, 0x20, size=(M, K))).astype(np.uint8) | (rng.integers(0, 2, size=(M, K)).astype(np.uint8) << 7)
+    B = (0x28 + rng.integers(0, 0x20, size=(N, K))).astype(np.uint8) | (rng.integers(0, 2, size=(N, K)).astype(np.uint8) << 7)
+    check_mm(oracle, native, cuda, A, B, [0.5], [2.0], kernel=kernel, tol=MM_TOL)
+
+
+def test_gemm_full_size_c3_against_oracle(native, cuda, oracle):
+    """BASELINE configs[2]: M=512, K=N=4096 against the float64 oracle."""
+    rng = np.random.default_rng(1234)
+    A = clean_bytes(rng, (512, 4096))
+    B = clean_bytes(rng, (4096, 4096))
+    for kernel in (L.KERNEL_AUTO, L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256):
+        check_mm(oracle, native, cuda, A, B, [0.01], [0.01], kernel=kernel)
+
+
+def test_generic_kernel_unaligned(native, cuda, oracle):
+    rng = np.random.default_rng(9)
+    for (M, K, N) in [(33, 100, 17), (1, 7, 5), (3, 1, 2), (2, 1023, 65)]:
+        A = rng.integers(0, 256, size=(M, K), dtype=np.uint8)
+        B = rng.integers(0, 256, size=(N, K), dtype=np.uint8)
+        check_mm(oracle, native, cuda, A, B, [0.02], [0.5])  # auto -> generic (K % 16 != 0)
+    # unaligned views of a larger buffer (row stride != K, odd base address)
+    big = rng.integers(0, 256, size=(40, 300), dtype=np.uint8)
+    tA = dev(big, cuda)[1:9, 3:259]      # (8, 256), stride 300, base + 303
+    tB = dev(big, cuda)[10:40, 5:261]    # (30, 256)
+    got = native.fp8_scaled_mm(tA, tB, torch.ones(1), torch.ones(1)).cpu().numpy()
+    exact = oracle.scaled_mm(big[1:9, 3:259], big[10:40, 5:261], [1.0], [1.0], accumulate="f64")
+    bound = oracle.abs_dot_bound(big[1:9, 3:259], big[10:40, 5:261], [1.0], [1.0])
+    assert np.all(np.abs(got - exact) <= MM_TOL * bound + 1e-30)
+
+
+def test_padded_row_stride_no_copy(native, cuda, oracle):
+    """lda / ldb > K (16-byte aligned): handled by the tuned kernels without a copy."""
+    rng = np.random.default_rng(10)
+    bufA = clean_bytes(rng, (64, 512))
+    bufB = clean_bytes(rng, (96, 512))
+    tA, tB = dev(bufA, cuda)[:, :256], dev(bufB, cuda)[:, :256]
+    got = native.fp8_scaled_mm(tA, tB, torch.ones(1), torch.ones(1)).cpu().numpy()
+    exact = oracle.scaled_mm(bufA[:, :256], bufB[:, :256], [1.0], [1.0], accumulate="f64")
+    assert np.all(np.abs(got - exact) <= MFMA_TOL * oracle.abs_dot_bound(bufA[:, :256], bufB[:, :256], [1.0], [1.0]) + 1e-30)
+    x = dev(bufA, cuda)[3:4, :256]
+    got = native.fp8_scaled_mm(x, tB, torch.ones(1), torch.ones(1)).cpu().numpy()
+    exact = oracle.scaled_mm(bufA[3:4, :256], bufB[:, :256], [1.0], [1.0], accumulate="f64")
+    assert np.all(np.abs(got - exact) <= MM_TOL * oracle.abs_dot_bound(bufA[3:4, :256], bufB[:, :256], [1.0], [1.0]) + 1e-30)
+
+
+@pytest.mark.parametrize("out_dtype", [None, torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [1, 48])
+def test_fused_epilogue(native, cuda, oracle, out_dtype, M):
+    """+ bias, * scale_result, cast - in the reference's order (fp8_mps_patch.py:94-104)."""
+    rng = np.random.default_rng(31 + M)
+    K, N = 512, 136
+    A = clean_bytes(rng, (M, K))
+    B = clean_bytes(rng, (N, K))
+    bias = rng.standard_normal(N).astype(np.float32)
+    check_mm(oracle, native, cuda, A, B, [0.01], [0.02], bias=bias, scale_result=0.5, out_dtype=out_dtype)
+    check_mm(oracle, native, cuda, A, B, [0.01], [0.02], bias=bias, out_dtype=out_dtype)
+    # bias in bf16, as a bf16 model would pass it
+    bb = torch.from_numpy(bias).to(torch.bfloat16)
+    got = native.fp8_scaled_mm(dev(A, cuda), dev(B, cuda), torch.tensor([0.01]), torch.tensor([0.02]),
+                               bias=bb.to(cuda), out_dtype=torch.float32).cpu().numpy()
+    exact = oracle.scaled_mm(A, B, [0.01], [0.02], accumulate="f64") + bb.float().numpy()[None, :]
+    bound = oracle.abs_dot_bound(A, B, [0.01], [0.02]) + np.abs(bb.float().numpy())[None, :]
+    assert np.all(np.abs(got - exact) <= (MFMA_TOL if M > 1 else MM_TOL) * bound + 1e-30)
+
+
+def test_empty_and_degenerate(native, cuda):
+    z = lambda *s: torch.zeros(*s, dtype=torch.uint8, device=cuda)
+    one = torch.ones(1)
+    assert native.fp8_scaled_mm(z(0, 64), z(8, 64), one, one).shape == (0, 8)
+    assert native.fp8_scaled_mm(z(4, 64), z(0, 64), one, one).shape == (4, 0)
+    out = native.fp8_scaled_mm(z(4, 0), z(8, 0), one, one)
+    assert out.shape == (4, 8) and not out.any()
+    with pytest.raises(AssertionError):
+        native.fp8_scaled_mm(z(4, 64), z(8, 32), one, one)
+    with pytest.raises(AssertionError):
+        native.fp8_scaled_mm(z(4, 64).float(), z(8, 64), one, one)
+    with pytest.raises(AssertionError):
+        native.fp8_scaled_mm(z(4, 64), z(8, 64), torch.ones(3), one)
+    with pytest.raises(L.Fp8miError):
+        native.fp8_scaled_mm(z(4, 64), z(8, 64), one, one, kernel=L.KERNEL_GEMV)
+
+
+# ---------------------------------------------------------------------------
+# the reference's own accuracy tests, restated (test_fp8_metal.py:97-218)
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("M,K,N", [(64, 256, 128), (128, 256, 64), (1, 512, 256), (1, 4096, 4096), (4, 4096, 4096)])
+def test_matmul_accuracy_vs_fp32(native, cuda, oracle, M, K, N):
+    g = torch.Generator().manual_seed(1234)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g)
+    ref = (A @ B.T).numpy()
+    Aq, sa = native.fp8_quantize(A.to(cuda))
+    Bq, sb = native.fp8_quantize(B.to(cuda))
+    out = native.fp8_scaled_mm(Aq, Bq, sa, sb)
+    assert oracle.rel_rmse(out.cpu().numpy(), ref) < REL_RMSE_GATE
+    # and the GPU agrees with the CPU oracle run on the same bytes, to fp32 rounding
+    exact = oracle.scaled_mm(Aq.cpu().numpy(), Bq.cpu().numpy(), sa.cpu().numpy(), sb.cpu().numpy(), accumulate="f64")
+    bound = oracle.abs_dot_bound(Aq.cpu().numpy(), Bq.cpu().numpy(), sa.cpu().numpy(), sb.cpu().numpy())
+    assert np.all(np.abs(out.cpu().numpy() - exact) <= (MFMA_TOL if M > 1 else MM_TOL) * bound + 1e-30)
+    if M > 1:  # amax-quantised gaussians: the MFMA result is far closer than its worst case
+        assert np.sqrt(np.mean((out.cpu().numpy() - exact) ** 2)) <= 2e-5 * np.sqrt(np.mean(bound ** 2))
+    assert torch.equal(native.fp8_scaled_mm_auto(Aq, Bq, sa, sb), out)
+    assert torch.equal(native.fp8_scaled_mm_fast(Aq, Bq, sa, sb), out)
+
+
+# ---------------------------------------------------------------------------
+# size-independent properties at BASELINE sizes
+# ---------------------------------------------------------------------------
+
+def test_properties_flux_shape(native, cuda):
+    """FLUX linear M=4096, K=3072, N=12288 (BASELINE configs[3]): power-of-two
+    scale linearity is exact, column shards reproduce the full product bit for
+    bit (what the N-sharded multi-GPU path relies on), K-splitting is additive."""
+    g = torch.Generator(device=cuda).manual_seed(7)
+    M, K, N = 4096, 3072, 12288
+    A = torch.randint(0, 256, (M, K), dtype=torch.uint8, device=cuda, generator=g)
+    B = torch.randint(0, 256, (N, K), dtype=torch.uint8, device=cuda, generator=g)
+    A[(A & 0x7F) == 0x7F] = 0x3C
+    B[(B & 0x7F) == 0x7F] = 0x3C
+    one = torch.ones(1, device=cuda)
+    full = native.fp8_scaled_mm(A, B, one, one)
+    assert torch.isfinite(full).all()
+    assert torch.equal(native.fp8_scaled_mm(A, B, one * 4, one * 0.5), full * 2)
+    shard = native.fp8_scaled_mm(A, B[1536:3072], one, one, kernel=L.KERNEL_GEMM_256)
+    assert torch.equal(shard, native.fp8_scaled_mm(A, B, one, one, kernel=L.KERNEL_GEMM_256)[:, 1536:3072])
+    h = 1536
+    parts = native.fp8_scaled_mm(A[:, :h], B[:, :h], one, one) + native.fp8_scaled_mm(A[:, h:], B[:, h:], one, one)
+    mag = native.fp8_scaled_mm(A & 0x7F, B & 0x7F, one, one)  # sum |a||b|
+    assert bool(((parts - full).abs() <= 2 * MFMA_TOL * mag + 1e-30).all())
+    # the transposed problem gives the transposed result
+    tr = native.fp8_scaled_mm(B[:2048], A[:1024], one, one)
+    assert bool(((tr.t() - full[:1024, :2048]).abs() <= 2 * MFMA_TOL * mag[:1024, :2048]).all())
+
+
+def test_gemv_equals_gemm_row(native, cuda):
+    """M == 1 through the GEMV kernel vs the same row through the MFMA kernel."""
+    g = torch.Generator(device=cuda).manual_seed(8)
+    K, N = 14336, 4096
+    x = torch.randint(0, 126, (1, K), dtype=torch.uint8, device=cuda, generator=g)
+    W = torch.randint(0, 126, (N, K), dtype=torch.uint8, device=cuda, generator=g)
+    s = torch.tensor([0.01], device=cuda)
+    a = native.fp8_scaled_mm(x, W, s, s, kernel=L.KERNEL_GEMV)
+    b = native.fp8_scaled_mm(x, W, s, s, kernel=L.KERNEL_GEMM_128)
+    mag = a.abs()  # all operands are non-negative here: sum|a||b| = the result
+    assert bool(((a - b).abs() <= MFMA_TOL * mag).all())

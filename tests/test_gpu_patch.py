@@ -1,0 +1,165 @@
+"""GPU (MI355X): the monkey-patch surface end to end, restating the reference's
+integration tests (test_fp8_metal.py:318-705, test_mps_vs_cpu.py:283-357,
+validate_fix.py:50-160) with "cuda" (PyTorch-ROCm) in the role of "mps"."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+F8 = torch.float8_e4m3fn
+REL_TOL = 0.15  # the reference's FP8_E4M3FN_RELATIVE_TOLERANCE (test_fp8_metal.py:32)
+
+
+def bytes_of(t):
+    return t.view(torch.uint8).cpu().numpy()
+
+
+def test_to_fp8_shapes_dtypes_devices(patch, native, cuda, oracle):
+    """test_fp8_metal.py:352-465."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4, 8, generator=g)
+    xd = x.to(cuda)
+    for y in (xd.to(F8), xd.to(dtype=F8), xd.to(cuda, F8), x.to(cuda, F8), x.to(device="cuda", dtype=F8),
+              xd.to(torch.device("cuda", 0), dtype=F8, non_blocking=True)):
+        assert y.dtype == F8 and y.device.type == "cuda" and y.shape == (4, 8)
+        assert np.array_equal(bytes_of(y), oracle.encode(x.numpy()))
+    for src in (torch.float16, torch.bfloat16, torch.float32):
+        xs = torch.randn(4, 4, generator=g).to(src)
+        y = xs.to(cuda).to(F8)
+        assert np.array_equal(bytes_of(y), oracle.encode(xs.float().numpy()))
+    e = torch.empty(0, device=cuda).to(F8)
+    assert e.dtype == F8 and e.numel() == 0
+    s = torch.tensor([3.14], device=cuda).to(F8)
+    assert s.shape == (1,) and abs(float(s.to(torch.float32).cpu()) - 3.14) / 3.14 < REL_TOL
+    big = torch.randn(128, 256, generator=g)
+    assert np.array_equal(bytes_of(big.to(cuda).to(F8)), oracle.encode(big.numpy()))
+    nc = torch.randn(16, 32, generator=g).to(cuda).t()  # non-contiguous source
+    assert np.array_equal(bytes_of(nc.to(F8)), oracle.encode(nc.cpu().numpy()))
+
+
+def test_value_preservation_no_auto_scaling(patch, native, cuda, golden_dir):
+    """test_fp8_metal.py:582-705, validate_fix.py: .to() must not rescale; bytes
+    equal the reference spec's for every value list the reference tests use."""
+    kat = json.load(open(os.path.join(golden_dir, "kat.json")))
+    for name, pairs in kat["value_lists"].items():
+        x = torch.tensor([p[0] for p in pairs], dtype=torch.float32, device=cuda)
+        y = x.to(F8)
+        assert bytes_of(y).tolist() == [p[1] for p in pairs], name
+        back = y.to(torch.float32)
+        for v, b in zip(x.cpu().tolist(), back.cpu().tolist()):
+            if abs(v) >= 0.015625:
+                assert abs(b - min(max(v, -448.0), 448.0)) <= REL_TOL * abs(v), (name, v, b)
+    one = torch.tensor([1.0], device=cuda).to(F8)
+    assert float(one.to(torch.float32).cpu()) == 1.0  # 1.0 -> 1.0, not 448 (test_fp8_metal.py:660-675)
+
+
+def test_torch_cpu_bytes_agree(patch, native, cuda):
+    """test_mps_vs_cpu.py:283-357: device bytes == torch-CPU bytes for [0.5,1,2,10,100]."""
+    v = torch.tensor([0.5, 1.0, 2.0, 10.0, 100.0])
+    cpu_bytes = patch._original_tensor_to(v, F8).view(torch.uint8)
+    assert torch.equal(v.to(cuda).to(F8).view(torch.uint8).cpu(), cpu_bytes)
+
+
+def test_fp8_cpu_to_device_is_byte_exact(patch, native, cuda):
+    """test_fp8_metal.py:467-483: pre-quantised CPU weights move as raw bytes."""
+    raw = torch.arange(256, dtype=torch.uint8).repeat(3)
+    w = raw.view(F8)
+    for moved in (w.to(cuda), w.to("cuda"), w.to(device=cuda), w.to(cuda, F8), w.to(cuda, non_blocking=True)):
+        assert moved.dtype == F8 and moved.device.type == "cuda"
+        assert torch.equal(moved.view(torch.uint8).cpu(), raw)
+    e5 = raw.view(torch.float8_e5m2).to(cuda)
+    assert e5.dtype == torch.float8_e5m2 and torch.equal(e5.view(torch.uint8).cpu(), raw)
+    # dtype given with the move: honoured (the reference drops it)
+    h = w.to(cuda, torch.float16)
+    assert h.dtype == torch.float16 and h.device.type == "cuda"
+
+
+def test_fp8_on_device_to_float(patch, native, cuda, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "decode_256.json")))
+    w = torch.arange(256, dtype=torch.uint8, device=cuda).view(F8)
+    assert w.to(F8) is w and w.to(cuda) is not None
+    h = w.to(torch.float16)
+    assert np.array_equal(h.cpu().view(torch.int16).numpy().view(np.uint16), np.array(g["f16_bits"], np.uint16))
+    f = w.to(torch.float32)
+    assert np.array_equal(f.cpu().numpy().view(np.uint32), np.array(g["f32_bits"], np.uint32))
+    assert torch.equal(w.to(torch.bfloat16).float(), f)
+    assert torch.equal(w.to(torch.float64).cpu(), f.double().cpu())
+    assert torch.equal(w.to(dtype=torch.float32, device=cuda), f)
+    assert w.reshape(16, 16).to(torch.float16).shape == (16, 16)
+    back = w.to("cpu")  # device -> CPU is torch's own path
+    assert back.device.type == "cpu" and torch.equal(back.view(torch.uint8), torch.arange(256, dtype=torch.uint8))
+
+
+def test_copy_scenarios(patch, native, cuda, oracle):
+    """test_fp8_metal.py:486-579."""
+    raw = torch.arange(256, dtype=torch.uint8)
+    dst = torch.empty(256, dtype=F8, device=cuda)
+    assert dst.copy_(raw.view(F8)) is dst                      # CPU fp8 -> device fp8 (weight load)
+    assert torch.equal(dst.view(torch.uint8).cpu(), raw)
+    dst2 = torch.empty(256, dtype=F8, device=cuda)
+    dst2.copy_(dst.flip(0))                                      # device fp8 -> device fp8 (stochastic rounding path)
+    assert torch.equal(dst2.view(torch.uint8).cpu(), raw.flip(0))
+    src = torch.tensor([[1.0, 2.5, -3.0, 0.5], [10.0, -8.0, 0.0, 100.0]], device=cuda)  # test_fp8_metal.py:527-528
+    d3 = torch.empty(2, 4, dtype=F8, device=cuda)
+    assert d3.copy_(src) is d3
+    assert np.array_equal(bytes_of(d3), oracle.encode(src.cpu().numpy()))
+    d4 = torch.empty(2, 4, dtype=F8, device=cuda)
+    d4.copy_(src.cpu().to(torch.bfloat16))                       # CPU bf16 source
+    assert np.array_equal(bytes_of(d4), oracle.encode(src.cpu().numpy()))
+    d5 = torch.empty(3, 4, dtype=F8, device=cuda)
+    d5.copy_(torch.tensor([1.0, 5.0, 10.0, 50.0], device=cuda))  # broadcast (validate_fix.py:110)
+    assert bytes_of(d5).tolist() == [oracle.encode(np.array([1.0, 5.0, 10.0, 50.0], np.float32)).tolist()] * 3
+    f = torch.zeros(4, device=cuda)
+    f.copy_(torch.ones(4))                                       # nothing fp8: untouched path
+    assert float(f.sum().cpu()) == 4.0
+
+
+def test_patched_scaled_mm(patch, native, cuda, oracle):
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(16, 32, generator=g)
+    B = torch.randn(32, 32, generator=g)  # (N, K)
+    Aq, sa = native.fp8_quantize(A.to(cuda))
+    Bq, sb = native.fp8_quantize(B.to(cuda))
+    a8, b8 = Aq.view(F8), Bq.view(F8)
+    exact = oracle.scaled_mm(Aq.cpu().numpy(), Bq.cpu().numpy(), sa.cpu().numpy(), sb.cpu().numpy())
+    for out in (torch._scaled_mm(a8, b8.t(), scale_a=sa, scale_b=sb),
+                torch._scaled_mm(a8, b8.t(), sa, sb),
+                torch._scaled_mm(Aq, Bq.t(), scale_a=sa, scale_b=sb, out_dtype=torch.float32),
+                torch._scaled_mm(a8, b8.t().contiguous(), scale_a=sa, scale_b=sb)):  # row-major `other`: copied
+        assert out.shape == (16, 32) and out.dtype == torch.float32 and out.device.type == "cuda"
+        assert np.allclose(out.cpu().numpy(), exact, rtol=1e-3, atol=1e-3)  # MFMA accumulation, see test_gpu_parity.MFMA_TOL
+    assert oracle.rel_rmse(exact, (A @ B.T).numpy()) < 0.06
+    bias = torch.randn(32, generator=g).to(cuda)
+    out = torch._scaled_mm(a8, b8.t(), scale_a=sa, scale_b=sb, bias=bias, out_dtype=torch.bfloat16)
+    assert out.dtype == torch.bfloat16
+    assert np.allclose(out.float().cpu().numpy(), exact + bias.cpu().numpy()[None, :], rtol=2e-2, atol=2e-2)
+    out = torch._scaled_mm(a8, b8.t())  # default scales = 1 (fp8_mps_patch.py:87-90)
+    exact1 = oracle.scaled_mm(Aq.cpu().numpy(), Bq.cpu().numpy(), [1.0], [1.0], accumulate="f64")
+    bound1 = oracle.abs_dot_bound(Aq.cpu().numpy(), Bq.cpu().numpy(), [1.0], [1.0])
+    assert np.all(np.abs(out.cpu().numpy() - exact1) <= 1e-3 * bound1)  # MFMA_TOL
+    # per-row scales in the (M,1) / (1,N) layout torch >= 2.5 passes
+    ra = torch.rand(16, 1, device=cuda) + 0.5
+    rb = torch.rand(1, 32, device=cuda) + 0.5
+    out = torch._scaled_mm(a8, b8.t(), scale_a=ra, scale_b=rb)
+    exp = oracle.scaled_mm(Aq.cpu().numpy(), Bq.cpu().numpy(), ra.cpu().numpy().ravel(), rb.cpu().numpy().ravel())
+    assert np.allclose(out.cpu().numpy(), exp, rtol=1e-3, atol=1e-3)
+
+
+def test_fp8_linear_call_site_flux_shapes(patch, native, cuda, oracle):
+    """A ComfyUI-style fp8 linear (x.to(fp8) -> _scaled_mm(w.t()) -> bf16) at a
+    FLUX projection shape, unchanged call site."""
+    g = torch.Generator().manual_seed(9)
+    M, K, N = 256, 3072, 1536
+    w = (torch.randn(N, K, generator=g) * 0.05).to(cuda)
+    x = torch.randn(M, K, generator=g).to(cuda)
+    w8 = w.to(F8)                                  # weight load: value-preserving encode
+    x8 = x.to(F8)
+    one = torch.ones((), device=cuda)
+    y = torch._scaled_mm(x8, w8.t(), scale_a=one, scale_b=one, out_dtype=torch.bfloat16)
+    ref = x @ w.t()
+    assert y.shape == (M, N) and y.dtype == torch.bfloat16
+    assert oracle.rel_rmse(y.float().cpu().numpy(), ref.cpu().numpy()) < 0.06
