@@ -49,10 +49,13 @@ def _worker(rank, world, port, chunks, per_row, with_bias, q):
         assert sorted(torch.cat(rows).tolist()) == list(range(N))
         y = lin(x, sa)
         assert y.shape == (M, N) and y.stride() == (1, M)  # .t() view of the gathered C^T
-        ref = o.scaled_mm(x.numpy(), W.numpy(), sa.numpy(), sb.numpy())
+        ref = o.scaled_mm(x.numpy(), W.numpy(), sa.numpy(), sb.numpy(), accumulate="f64")
+        bound = o.abs_dot_bound(x.numpy(), W.numpy(), sa.numpy(), sb.numpy())
         if bias is not None:
             ref = ref + bias.numpy()[None, :]
-        ok = np.allclose(y.numpy(), ref, rtol=1e-6, atol=1e-6)
+            bound = bound + np.abs(bias.numpy())[None, :]
+        # float32 products summed in another order (transposed blocks): fp32 rounding only
+        ok = bool(np.all(np.abs(y.numpy() - ref) <= 4e-6 * bound + 1e-30))
         # identical on every rank
         g = [torch.empty_like(y.contiguous()) for _ in range(world)]
         dist.all_gather(g, y.contiguous())
