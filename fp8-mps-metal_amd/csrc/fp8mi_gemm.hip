@@ -24,8 +24,13 @@
 //     address and again on the fragment read.  Rows >= M / N and the K tail
 //     are masked by pointing the lane outside the buffer (hardware returns 0,
 //     and a zero byte is +0.0 in e4m3).
-//   * pipeline: double-buffered LDS, the loads of K-step t+1 are issued before
-//     the MFMAs of step t, one barrier per step.
+//   * pipeline: an NSTAGE-deep LDS ring.  NSTAGE-1 K-steps of LDS-DMA stay in
+//     flight ACROSS the per-step barrier: the wait is a counted
+//     `s_waitcnt vmcnt(n)` (n = loads of the newer stages), the barrier a raw
+//     s_barrier - a __syncthreads() would drain the DMA queue (vmcnt(0)) and
+//     expose a full memory round trip per K-step (measured on the 2-stage
+//     version of this kernel: 49-66 % of wave time parked in waits,
+//     profiles/r01_v1_*).  One barrier per K-step.
 //   * output orientation: the W fragment is the MFMA "A" operand and the X
 //     fragment the "B" operand, so each lane ends up with 4 CONSECUTIVE n of
 //     one row m in an accumulator register quad -> one 16-byte store.
@@ -50,8 +55,10 @@ constexpr int kScaleOne = 0x7F7F7F7F;  // E8M0 127 = 2^0 in every byte
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NSTAGE_>
 struct Cfg {
+    static constexpr int NSTAGE = NSTAGE_;
+    static constexpr int PF = NSTAGE_ - 1;  // K-steps of loads in flight
     static constexpr int kWavesM = BM / WM;
     static constexpr int kWavesN = BN / WN;
     static constexpr int kWaves = kWavesM * kWavesN;
@@ -64,6 +71,8 @@ struct Cfg {
     static constexpr int kGroupsPerWave = kGroups / kWaves;
     static constexpr int kStageBytes = (BM + BN) * BK;
     static_assert(kGroups % kWaves == 0, "staging groups must divide evenly over the waves");
+    static_assert(NSTAGE_ >= 2 && (NSTAGE_ - 2) * kGroupsPerWave <= 63, "vmcnt is a 6-bit counter");
+    static_assert(NSTAGE_ * kStageBytes <= 160 * 1024, "LDS is 160 KiB per CU");
 };
 
 // one K-step's fragments -> MFMAs
@@ -126,6 +135,32 @@ FP8MI_DEVICE void issue_stage(const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra,
     }
 }
 
+template <int N>
+FP8MI_DEVICE void wait_loads_and_lds()
+{
+    // this wave's LDS-DMA except the N youngest have landed; its ds_reads are done
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+
+template <typename C>
+FP8MI_DEVICE void wait_stage(int newer_stages)
+{
+    constexpr int G = C::kGroupsPerWave;
+    if (C::PF >= 2 && newer_stages >= C::PF - 1) wait_loads_and_lds<(C::PF - 1) * G>();
+    else if (C::PF >= 5 && newer_stages == 3) wait_loads_and_lds<3 * G>();
+    else if (C::PF >= 4 && newer_stages == 2) wait_loads_and_lds<2 * G>();
+    else if (C::PF >= 3 && newer_stages == 1) wait_loads_and_lds<1 * G>();
+    else wait_loads_and_lds<0>();
+}
+
+template <typename C>
+FP8MI_DEVICE void issue_any(const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
+                            uint8_t *stage, int wave, int step, int nk, bool ktail, int64_t K)
+{
+    if (ktail && step == nk - 1) issue_stage<C, true>(pl, ra, rb, stage, wave, step * BK, K);
+    else issue_stage<C, false>(pl, ra, rb, stage, wave, step * BK, K);
+}
+
 template <typename C, bool SCRUB>
 FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra,
                            __amdgpu_buffer_rsrc_t rb, int wave, int wm0, int wn0, uint32_t off1, uint32_t off2,
@@ -140,25 +175,33 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
     const int nk = (int)((K + BK - 1) / BK);
     const bool ktail = (K % BK) != 0;  // then the last step is staged with per-lane K masking
     if (nk == 0) return;
-    if (nk == 1 && ktail) issue_stage<C, true>(pl, ra, rb, smem, wave, 0, K);
-    else issue_stage<C, false>(pl, ra, rb, smem, wave, 0, K);
-    __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and joins the waves
-    int cur = 0;
+
+    // prologue: PF stages in flight (stage s -> ring slot s)
+#pragma unroll
+    for (int s = 0; s < C::PF; ++s)
+        if (s < nk) issue_any<C>(pl, ra, rb, smem + s * C::kStageBytes, wave, s, nk, ktail, K);
+
+    int slot = 0;             // ring slot of step t
+    int fill = C::PF % C::NSTAGE;  // ring slot the next issue goes to (= slot of step t-1)
     for (int t = 0; t < nk; ++t) {
-        uint8_t *nxt = smem + (cur ^ 1) * C::kStageBytes;
-        if (t + 2 < nk || (t + 2 == nk && !ktail)) issue_stage<C, false>(pl, ra, rb, nxt, wave, (t + 1) * BK, K);
-        else if (t + 2 == nk) issue_stage<C, true>(pl, ra, rb, nxt, wave, (t + 1) * BK, K);
-        compute_step<C, SCRUB>(smem + cur * C::kStageBytes, wm0, wn0, off1, off2, acc);
-        __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done reading `cur`
-        cur ^= 1;
+        // stage t has landed for this wave once at most the newer stages' loads are outstanding
+        wait_stage<C>(min(C::PF - 1, nk - 1 - t));
+        __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave is done reading slot of step t-1
+        if (t + C::PF < nk) issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, t + C::PF, nk, ktail, K);
+        compute_step<C, SCRUB>(smem + slot * C::kStageBytes, wm0, wn0, off1, off2, acc);
+        slot = (slot + 1 == C::NSTAGE) ? 0 : slot + 1;
+        fill = (fill + 1 == C::NSTAGE) ? 0 : fill + 1;
     }
+    // all loads were waited for in the last iteration (newer_stages == 0); make the ring reusable
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__((Cfg<BM, BN, WM, WN>::kThreads)) void gemm_kernel(MMParams p, int tiles_m, int vec_store)
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE>::kThreads)) void gemm_kernel(MMParams p, int tiles_m, int vec_store)
 {
-    using C = Cfg<BM, BN, WM, WN>;
-    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * C::kStageBytes];
+    using C = Cfg<BM, BN, WM, WN, NSTAGE>;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[NSTAGE * C::kStageBytes];
 
     // ---- XCD-aware, bijective block -> tile map (m fastest) -------------
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -267,15 +310,15 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN>::kThreads)) void gemm_kernel(M
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NSTAGE>
 int launch(const MMParams &p, hipStream_t s)
 {
-    using C = Cfg<BM, BN, WM, WN>;
+    using C = Cfg<BM, BN, WM, WN, NSTAGE>;
     const int64_t tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     if (tm * tn > 0x7FFFFFFF) return FP8MI_E_UNSUPPORTED;
     const int esz = p.out_dtype == FP8MI_F32 ? 4 : 2;
     const int vec = ((p.ldc % 4) == 0 && (((uintptr_t)p.C) % (4 * esz)) == 0) ? 1 : 0;
-    FP8MI_LAUNCH((gemm_kernel<BM, BN, WM, WN>), dim3((unsigned)(tm * tn)), dim3(C::kThreads), s, p, (int)tm,
+    FP8MI_LAUNCH((gemm_kernel<BM, BN, WM, WN, NSTAGE>), dim3((unsigned)(tm * tn)), dim3(C::kThreads), s, p, (int)tm,
                        vec);
     return (int)hipGetLastError();
 }
@@ -298,9 +341,9 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
         else variant = FP8MI_KERNEL_GEMM_128x64;
     }
     switch (variant) {
-    case FP8MI_KERNEL_GEMM_128: return launch<128, 128, 64, 64>(p, s);
-    case FP8MI_KERNEL_GEMM_128x64: return launch<128, 64, 64, 32>(p, s);
-    case FP8MI_KERNEL_GEMM_256: return launch<256, 256, 128, 64>(p, s);
+    case FP8MI_KERNEL_GEMM_128: return launch<128, 128, 64, 64, 4>(p, s);     // 4 x 32 KiB ring
+    case FP8MI_KERNEL_GEMM_128x64: return launch<128, 64, 64, 32, 6>(p, s);    // 6 x 24 KiB ring
+    case FP8MI_KERNEL_GEMM_256: return launch<256, 256, 128, 64, 2>(p, s);     // 2 x 64 KiB
     default: return FP8MI_E_ENUM;
     }
 }
