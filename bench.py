@@ -57,17 +57,40 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+DATA_MODE = "gauss"
+
+
 def clean_bytes(shape, dev, gen):
-    """Uniform random e4m3 bytes with the two NaN patterns remapped (0x7F->0x7E,
-    0xFF->0xFE): throughput inputs per SURVEY 8d; NaN-byte parity is a test."""
-    b = torch.randint(0, 256, shape, dtype=torch.uint8, device=dev, generator=gen)
-    return torch.where((b & 0x7F) == 0x7F, b ^ 1, b)
+    """Synthetic e4m3 operand bytes (SURVEY 8d offers both):
+      gauss   - seeded N(0,1) values amax-quantised to e4m3 (scale 448/amax) with
+                the product's own encode kernel: the bit statistics of real
+                weights / activations (default);
+      uniform - uniformly random bytes with the two NaN patterns remapped
+                (0x7F->0x7E, 0xFF->0xFE): every exponent equally likely, the
+                worst case for switching power (the chip clocks lower on it);
+      zeros   - all-zero bytes (upper bound on clocks; never a reported number)."""
+    if DATA_MODE == "zeros":
+        return torch.zeros(shape, dtype=torch.uint8, device=dev)
+    if DATA_MODE == "uniform":
+        b = torch.randint(0, 256, shape, dtype=torch.uint8, device=dev, generator=gen)
+        return torch.where((b & 0x7F) == 0x7F, b ^ 1, b)
+    import fp8_mi355x_native as native
+    n = 1
+    for d in shape:
+        n *= d
+    out = torch.empty(n, dtype=torch.uint8, device=dev)
+    chunk = 1 << 26
+    for i in range(0, n, chunk):
+        m = min(chunk, n - i)
+        x = torch.randn(m, device=dev, generator=gen)
+        out[i:i + m] = native.fp8_quantize(x)[0]
+    return out.reshape(shape)
 
 
 class Workload:
     """One named workload: buffers + a `launch(i)` closure calling the C ABI."""
 
-    def __init__(self, name, dev, world=1, rank=0, kernel=L.KERNEL_AUTO):
+    def __init__(self, name, dev, world=1, rank=0, kernel=L.KERNEL_AUTO, nbuf=None):
         self.name, self.dev, self.world, self.rank, self.kernel = name, dev, world, rank, kernel
         self.lib = L.load()
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -80,7 +103,7 @@ class Workload:
             self.N = Nl
             self.out_dtype = torch.bfloat16 if name == "flux" else torch.float32
             esz = 2 if name == "flux" else 4
-            nbuf = max(2, -(-int(1.25 * CACHE_BYTES) // (Nl * K)))
+            nbuf = nbuf or max(2, -(-int(1.25 * CACHE_BYTES) // (Nl * K)))
             self.A = clean_bytes((M, K), dev, torch.Generator(device=dev).manual_seed(99))  # replicated activations
             self.Bs = [clean_bytes((Nl, K), dev, gen) for _ in range(nbuf)]
             self.sa = torch.full((1,), 0.01, dtype=torch.float32, device=dev)
@@ -283,8 +306,8 @@ def load_traffic(name):
         return None
 
 
-def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info):
-    w = Workload(name, dev, world, rank, kernel)
+def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info, nbuf=None):
+    w = Workload(name, dev, world, rank, kernel, nbuf)
     dt, graphed = time_steps(w, steps, warmup, True, world)
     launches = steps * w.inner
     if w.unit_flops:
@@ -309,9 +332,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="auto", choices=["auto", "gemm", "gemv", "flux", "quantize", "dequant"])
     ap.add_argument("--kernel", type=int, default=L.KERNEL_AUTO, help="force an FP8MI_KERNEL_* id")
+    ap.add_argument("--nbuf", type=int, default=None, help="override the number of rotating weight buffers "
+                    "(1 = weights stay cache-resident; for sensitivity experiments only)")
+    ap.add_argument("--data", default="gauss", choices=["gauss", "uniform", "zeros"],
+                    help="operand byte distribution (see clean_bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
+    global DATA_MODE
+    DATA_MODE = args.data
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -335,13 +364,15 @@ def main():
         raise SystemExit("multi-GPU runs shard the FLUX linear (configs[3]); use --workload flux or auto")
 
     res = measure(primary, dev, args.steps, args.warmup, world, rank, args.kernel,
-                  with_cpu=(world == 1 and rank == 0 and not args.no_cpu_baseline), info=info)
+                  with_cpu=(world == 1 and rank == 0 and not args.no_cpu_baseline), info=info, nbuf=args.nbuf)
     line = {
         "metric": METRIC, "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
         "scaling": "strong" if primary == "flux" else "weak", "vs_baseline": None,
         "dtype": "fp8_e4m3fn (fp32 accumulate)" if primary in ("gemm", "gemv", "flux") else "u8",
-        "data": "synthetic (seeded uniform e4m3 bytes, NaN patterns remapped; weights rotate through > 256 MiB)",
+        "data": {"gauss": "synthetic (seeded N(0,1) amax-quantised to e4m3fn; weights rotate through > 256 MiB)",
+                 "uniform": "synthetic (seeded uniform e4m3 bytes, NaN patterns remapped; weights rotate through > 256 MiB)",
+                 "zeros": "synthetic (all-zero bytes; clock upper bound, not a reportable number)"}[args.data],
         "config": dict(res["config"], launches_per_step=res["launches_per_step"], hip_graph=res["hip_graph"],
                        parallelism=("N-column-sharded x%d + RCCL all-gather" % world) if world > 1 else "single GPU",
                        device=info["name"], arch=info["arch"], compute_units=info["compute_units"]),

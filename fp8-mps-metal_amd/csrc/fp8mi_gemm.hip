@@ -55,8 +55,9 @@ constexpr int kScaleOne = 0x7F7F7F7F;  // E8M0 127 = 2^0 in every byte
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int BM, int BN, int WM, int WN, int NSTAGE_>
+template <int BM, int BN, int WM, int WN, int NSTAGE_, bool PINGPONG_ = false>
 struct Cfg {
+    static constexpr bool PINGPONG = PINGPONG_;
     static constexpr int NSTAGE = NSTAGE_;
     static constexpr int PF = NSTAGE_ - 1;  // K-steps of loads in flight
     static constexpr int kWavesM = BM / WM;
@@ -73,14 +74,14 @@ struct Cfg {
     static_assert(kGroups % kWaves == 0, "staging groups must divide evenly over the waves");
     static_assert(NSTAGE_ >= 2 && (NSTAGE_ - 2) * kGroupsPerWave <= 63, "vmcnt is a 6-bit counter");
     static_assert(NSTAGE_ * kStageBytes <= 160 * 1024, "LDS is 160 KiB per CU");
+    static_assert(!PINGPONG_ || kWaves == 8, "the ping-pong schedule pairs waves w and w + 4 on one SIMD");
 };
 
-// one K-step's fragments -> MFMAs
+// one K-step's fragments: LDS -> registers
 template <typename C, bool SCRUB>
-FP8MI_DEVICE void compute_step(const uint8_t *stage, int a_row0 /* m */, int b_row0 /* n */, uint32_t off1,
-                               uint32_t off2, f32x4 (&acc)[C::TN][C::TM])
+FP8MI_DEVICE void load_frags(const uint8_t *stage, int a_row0 /* m */, int b_row0 /* n */, uint32_t off1, uint32_t off2,
+                             i32x8 (&xf)[C::TM], i32x8 (&wf)[C::TN])
 {
-    i32x8 xf[C::TM], wf[C::TN];
     const uint8_t *sa = stage + a_row0 * BK;                       // X rows (m) first ...
     const uint8_t *sB = stage + (C::kGroupsA * 8 + b_row0) * BK;   // ... then W rows (n)
 #pragma unroll
@@ -105,12 +106,27 @@ FP8MI_DEVICE void compute_step(const uint8_t *stage, int a_row0 /* m */, int b_r
 #pragma unroll
             for (int j = 0; j < 8; ++j) wf[t][j] = (int)scrub_nan4((uint32_t)wf[t][j]);
     }
+}
+
+// registers -> MFMAs (W fragment is the MFMA "A" operand, X fragment the "B" operand)
+template <typename C>
+FP8MI_DEVICE void mfma_all(const i32x8 (&xf)[C::TM], const i32x8 (&wf)[C::TN], f32x4 (&acc)[C::TN][C::TM])
+{
 #pragma unroll
     for (int tn = 0; tn < C::TN; ++tn)
 #pragma unroll
         for (int tm = 0; tm < C::TM; ++tm)
             acc[tn][tm] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0,
                                                                             kScaleOne, 0, kScaleOne);
+}
+
+template <typename C, bool SCRUB>
+FP8MI_DEVICE void compute_step(const uint8_t *stage, int a_row0, int b_row0, uint32_t off1, uint32_t off2,
+                               f32x4 (&acc)[C::TN][C::TM])
+{
+    i32x8 xf[C::TM], wf[C::TN];
+    load_frags<C, SCRUB>(stage, a_row0, b_row0, off1, off2, xf, wf);
+    mfma_all<C>(xf, wf, acc);
 }
 
 template <typename C>
@@ -134,6 +150,22 @@ FP8MI_DEVICE void issue_stage(const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra,
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, (int)vo, k0, 0, 0);
     }
 }
+
+// Diagnostic build only (-DFP8MI_STAMP, never shipped): per-phase cycle sums of
+// wave 0 of every workgroup, written over the first bytes of each C tile row 0.
+#ifdef FP8MI_STAMP
+#define STAMP(var)                                                                 \
+    do {                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        unsigned long long t_;                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        var = t_;                                                                  \
+    } while (0)
+__device__ unsigned long long g_stamp[256 * 8];
+#else
+#define STAMP(var) do { } while (0)
+#endif
 
 template <int N>
 FP8MI_DEVICE void wait_loads_and_lds()
@@ -164,7 +196,7 @@ FP8MI_DEVICE void issue_any(const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra, _
 template <typename C, bool SCRUB>
 FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra,
                            __amdgpu_buffer_rsrc_t rb, int wave, int wm0, int wn0, uint32_t off1, uint32_t off2,
-                           f32x4 (&acc)[C::TN][C::TM])
+                           int rot, f32x4 (&acc)[C::TN][C::TM])
 {
 #pragma unroll
     for (int tn = 0; tn < C::TN; ++tn)
@@ -176,33 +208,218 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
     const bool ktail = (K % BK) != 0;  // then the last step is staged with per-lane K masking
     if (nk == 0) return;
 
+    // The K loop is walked circularly from `rot` (a per-m-tile offset): the tiles
+    // that share a B panel run at the same time on one XCD, and if they all
+    // started at k = 0 each of them would wait out HBM latency on the same lines;
+    // staggered, each one fetches a different K range from HBM and finds the
+    // rest already in the XCD's L2.  (Only the summation order changes.)
+    int ks = rot;  // K-step the next issue loads
+    auto next_ks = [&]() { const int r = ks; ks = (ks + 1 == nk) ? 0 : ks + 1; return r; };
+
     // prologue: PF stages in flight (stage s -> ring slot s)
 #pragma unroll
     for (int s = 0; s < C::PF; ++s)
-        if (s < nk) issue_any<C>(pl, ra, rb, smem + s * C::kStageBytes, wave, s, nk, ktail, K);
+        if (s < nk) issue_any<C>(pl, ra, rb, smem + s * C::kStageBytes, wave, next_ks(), nk, ktail, K);
 
     int slot = 0;             // ring slot of step t
     int fill = C::PF % C::NSTAGE;  // ring slot the next issue goes to (= slot of step t-1)
+    unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+    (void)c_wait; (void)c_bar; (void)c_issue; (void)c_comp; (void)s0; (void)s1; (void)s2; (void)s3; (void)s4;
     for (int t = 0; t < nk; ++t) {
+        STAMP(s0);
         // stage t has landed for this wave once at most the newer stages' loads are outstanding
         wait_stage<C>(min(C::PF - 1, nk - 1 - t));
+        STAMP(s1);
         __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave is done reading slot of step t-1
-        if (t + C::PF < nk) issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, t + C::PF, nk, ktail, K);
+        STAMP(s2);
+        if (t + C::PF < nk) issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, next_ks(), nk, ktail, K);
+        STAMP(s3);
         compute_step<C, SCRUB>(smem + slot * C::kStageBytes, wm0, wn0, off1, off2, acc);
+        STAMP(s4);
+        c_wait += s1 - s0; c_bar += s2 - s1; c_issue += s3 - s2; c_comp += s4 - s3;
         slot = (slot + 1 == C::NSTAGE) ? 0 : slot + 1;
         fill = (fill + 1 == C::NSTAGE) ? 0 : fill + 1;
     }
+#ifdef FP8MI_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 256) {
+        g_stamp[blockIdx.x * 8 + 0] = c_wait; g_stamp[blockIdx.x * 8 + 1] = c_bar;
+        g_stamp[blockIdx.x * 8 + 2] = c_issue; g_stamp[blockIdx.x * 8 + 3] = c_comp;
+        g_stamp[blockIdx.x * 8 + 4] = nk;
+    }
+#endif
     // all loads were waited for in the last iteration (newer_stages == 0); make the ring reusable
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE>::kThreads)) void gemm_kernel(MMParams p, int tiles_m, int vec_store)
+// Ping-pong K loop (8 waves = two groups of 4; waves w and w + 4 share a SIMD).
+// Group 1 runs half a K-step behind group 0, so in every half-step one group is
+// in its MFMA phase (priority raised: the matrix pipe never idles waiting for
+// issue slots) while the other reads its fragments from LDS and issues the
+// LDS-DMA of a later stage.  Per half-step h (one raw barrier after each):
+//     h = 2t   : g0  issue(t+PF), frags(t) -> regs      g1  issue(t+PF), MFMA(t-1)
+//     h = 2t+1 : g0  MFMA(t), wait stage t+1            g1  frags(t) -> regs, wait stage t+1
+//     h = 2nk  :                                         g1  MFMA(nk-1)
+// Slot of stage t-1 is last read in h = 2t-1 and refilled from h = 2t; stage t+1
+// is complete (every wave's share, then the barrier) before h = 2t+2.  Both
+// groups execute exactly 2 barriers per K-step.
+template <typename C, bool SCRUB>
+FP8MI_DEVICE void run_tile_pingpong(const MMParams &p, uint8_t *smem, const StagePlan<C> &pl,
+                                    __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int wave, int wm0, int wn0,
+                                    uint32_t off1, uint32_t off2, int rot, f32x4 (&acc)[C::TN][C::TM])
 {
-    using C = Cfg<BM, BN, WM, WN, NSTAGE>;
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm) acc[tn][tm] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int64_t K = p.K;
+    const int nk = (int)((K + BK - 1) / BK);
+    const bool ktail = (K % BK) != 0;
+    if (nk == 0) return;
+    int ks = rot;
+    auto next_ks = [&]() { const int r = ks; ks = (ks + 1 == nk) ? 0 : ks + 1; return r; };
+
+#pragma unroll
+    for (int s = 0; s < C::PF; ++s)
+        if (s < nk) issue_any<C>(pl, ra, rb, smem + s * C::kStageBytes, wave, next_ks(), nk, ktail, K);
+    wait_stage<C>(min(C::PF - 1, nk - 1));  // stage 0
+    __builtin_amdgcn_s_barrier();
+
+    i32x8 xf[C::TM], wf[C::TN];
+    int slot = 0, fill = C::PF % C::NSTAGE;
+    if (wave < C::kWaves / 2) {
+        for (int t = 0; t < nk; ++t) {
+            // ---- h = 2t ----
+            if (t + C::PF < nk) issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, next_ks(), nk, ktail, K);
+            load_frags<C, SCRUB>(smem + slot * C::kStageBytes, wm0, wn0, off1, off2, xf, wf);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- h = 2t + 1 ----
+            __builtin_amdgcn_s_setprio(1);
+            mfma_all<C>(xf, wf, acc);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < nk) wait_stage<C>(min(C::PF - 1, nk - 2 - t));  // stage t+1
+            __builtin_amdgcn_s_barrier();
+            slot = (slot + 1 == C::NSTAGE) ? 0 : slot + 1;
+            fill = (fill + 1 == C::NSTAGE) ? 0 : fill + 1;
+        }
+    } else {
+        for (int t = 0; t < nk; ++t) {
+            // ---- h = 2t ----
+            if (t + C::PF < nk) issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, next_ks(), nk, ktail, K);
+            if (t > 0) {
+                __builtin_amdgcn_s_setprio(1);
+                mfma_all<C>(xf, wf, acc);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- h = 2t + 1 ----
+            load_frags<C, SCRUB>(smem + slot * C::kStageBytes, wm0, wn0, off1, off2, xf, wf);
+            if (t + 1 < nk) wait_stage<C>(min(C::PF - 1, nk - 2 - t));  // stage t+1 (also lgkmcnt(0))
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            slot = (slot + 1 == C::NSTAGE) ? 0 : slot + 1;
+            fill = (fill + 1 == C::NSTAGE) ? 0 : fill + 1;
+        }
+        // ---- h = 2 nk ----
+        mfma_all<C>(xf, wf, acc);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // ring reusable (NaN re-run) / everyone done before the epilogue
+}
+
+// Fused epilogue, in the reference's order (fp8_matmul.metal:144-146, then
+// fp8_mps_patch.py:94-104): (acc * sa) * sb, + bias, * scale_result, cast.
+// Lane (fr = lane & 15, fg = lane >> 4) holds, per 16x16 fragment (tn, tm), the
+// 4 consecutive columns n = tn*16 + 4 fg + j of row m = tm*16 + fr: one 16-byte
+// (fp32) or 8-byte (bf16 / f16) store.  Column scales and bias are loaded once
+// per lane, row scales once per fragment row; everything else is 32-bit math.
+template <typename C, int OUT>
+FP8MI_DEVICE void epilogue(const MMParams &p, const f32x4 (&acc)[C::TN][C::TM], int64_t m0, int64_t n0, int wm0,
+                           int wn0, int fr, int fg, int rows_m, int cols_n, int vec_store)
+{
+    const bool has_bias = p.bias != nullptr;
+    const float sr = p.scale_result ? p.scale_result[0] : 1.0f;
+    const bool has_sr = p.scale_result != nullptr;
+    float sbv[C::TN][4], bv[C::TN][4];
+    const float sb0 = p.scale_b[0];
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nl = min(wn0 + tn * 16 + fg * 4 + j, cols_n - 1);  // clamped: the value is unused past the edge
+            sbv[tn][j] = p.sb_row ? p.scale_b[n0 + nl] : sb0;
+            bv[tn][j] = has_bias ? load_as_float(p.bias, n0 + nl, p.bias_dtype) : 0.0f;
+        }
+    const float sa0 = p.scale_a[0];
+    constexpr int kEsz = OUT == FP8MI_F32 ? 4 : 2;
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm) {
+        const int ml = wm0 + tm * 16 + fr;
+        if (ml >= rows_m) continue;
+        const float sa = p.sa_row ? p.scale_a[m0 + ml] : sa0;
+        uint8_t *row = (uint8_t *)p.C + ((m0 + ml) * p.ldc + n0) * kEsz;
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) {
+            const int nl = wn0 + tn * 16 + fg * 4;
+            if (nl >= cols_n) continue;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float r = (acc[tn][tm][j] * sa) * sbv[tn][j];
+                if (has_bias) r = r + bv[tn][j];
+                if (has_sr) r = r * sr;
+                v[j] = r;
+            }
+            uint8_t *dst = row + nl * kEsz;
+            if (vec_store && nl + 3 < cols_n) {
+                if (OUT == FP8MI_F32) {
+                    *(f32x4 *)dst = f32x4{v[0], v[1], v[2], v[3]};
+                } else if (OUT == FP8MI_BF16) {
+                    __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1], h2 = (__bf16)v[2], h3 = (__bf16)v[3];
+                    *(u32x2 *)dst = u32x2{(uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16),
+                                          (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16)};
+                } else {
+                    _Float16 h0 = (_Float16)v[0], h1 = (_Float16)v[1], h2 = (_Float16)v[2], h3 = (_Float16)v[3];
+                    *(u32x2 *)dst = u32x2{(uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16),
+                                          (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16)};
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (nl + j < cols_n) {
+                        if (OUT == FP8MI_F32) ((float *)dst)[j] = v[j];
+                        else if (OUT == FP8MI_BF16) ((__bf16 *)dst)[j] = (__bf16)v[j];
+                        else ((_Float16 *)dst)[j] = (_Float16)v[j];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename C, bool SCRUB>
+FP8MI_DEVICE void run_tile_any(const MMParams &p, uint8_t *smem, const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra,
+                               __amdgpu_buffer_rsrc_t rb, int wave, int wm0, int wn0, uint32_t off1, uint32_t off2,
+                               int rot, f32x4 (&acc)[C::TN][C::TM])
+{
+    if constexpr (C::PINGPONG) run_tile_pingpong<C, SCRUB>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, rot, acc);
+    else run_tile<C, SCRUB>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, rot, acc);
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool PP>
+__global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP>::kThreads)) void gemm_kernel(MMParams p, int tiles_m, int vec_store)
+{
+    using C = Cfg<BM, BN, WM, WN, NSTAGE, PP>;
     __shared__ __attribute__((aligned(16))) uint8_t smem[NSTAGE * C::kStageBytes];
 
+    unsigned long long k0_ = 0, k1_ = 0, k2_ = 0; (void)k0_; (void)k1_; (void)k2_;
+    STAMP(k0_);
     // ---- XCD-aware, bijective block -> tile map (m fastest) -------------
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
@@ -243,8 +460,11 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE>::kThreads)) void gemm_
     const uint32_t off1 = (uint32_t)(fr * BK + ((fg ^ (fr >> 1)) << 4));
     const uint32_t off2 = (uint32_t)(fr * BK + (((4 + fg) ^ (fr >> 1)) << 4));
 
+    const int nk_all = (int)((p.K + BK - 1) / BK);
+    const int rot = (int)(((int64_t)tile_m * nk_all) / tiles_m);  // in [0, nk)
+
     f32x4 acc[C::TN][C::TM];
-    run_tile<C, false>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, acc);
+    run_tile_any<C, false>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, rot, acc);
 
     if (p.nan_zero) {
         int bad = 0;
@@ -262,68 +482,46 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE>::kThreads)) void gemm_
         __syncthreads();
         const int any_bad = *flag;
         __syncthreads();
-        if (any_bad) run_tile<C, true>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, acc);
+        if (any_bad) run_tile_any<C, true>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, rot, acc);
     }
 
+    STAMP(k1_);
     // ---- fused epilogue ---------------------------------------------------
-    const bool has_bias = p.bias != nullptr, has_sr = p.scale_result != nullptr;
-    const float sr = has_sr ? p.scale_result[0] : 1.0f;
-    const float sa0 = p.scale_a[0], sb0 = p.scale_b[0];
-#pragma unroll
-    for (int tm = 0; tm < C::TM; ++tm) {
-        const int64_t m = m0 + wm0 + tm * 16 + fr;
-        if (m >= p.M) continue;
-        const float sa = p.sa_row ? p.scale_a[m] : sa0;
-#pragma unroll
-        for (int tn = 0; tn < C::TN; ++tn) {
-            const int64_t n = n0 + wn0 + tn * 16 + fg * 4;
-            if (n >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t nj = min(n + j, p.N - 1);
-                const float sb = p.sb_row ? p.scale_b[nj] : sb0;
-                const float b = has_bias ? load_as_float(p.bias, nj, p.bias_dtype) : 0.0f;
-                v[j] = epilogue_value(acc[tn][tm][j], sa, sb, has_bias, b, has_sr, sr);
-            }
-            const int64_t idx = m * p.ldc + n;
-            if (vec_store && n + 3 < p.N) {
-                if (p.out_dtype == FP8MI_F32) {
-                    *(f32x4 *)((float *)p.C + idx) = f32x4{v[0], v[1], v[2], v[3]};
-                } else if (p.out_dtype == FP8MI_BF16) {
-                    __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1], h2 = (__bf16)v[2], h3 = (__bf16)v[3];
-                    u32x2 pk = {(uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16),
-                                (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16)};
-                    *(u32x2 *)((uint16_t *)p.C + idx) = pk;
-                } else {
-                    _Float16 h0 = (_Float16)v[0], h1 = (_Float16)v[1], h2 = (_Float16)v[2], h3 = (_Float16)v[3];
-                    u32x2 pk = {(uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16),
-                                (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16)};
-                    *(u32x2 *)((uint16_t *)p.C + idx) = pk;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (n + j < p.N) store_from_float(p.C, idx + j, v[j], p.out_dtype);
-            }
-        }
+    const int rows_m = (int)rows_a, cols_n = (int)rows_b;  // valid extent of this tile
+    if (p.out_dtype == FP8MI_F32) epilogue<C, FP8MI_F32>(p, acc, m0, n0, wm0, wn0, fr, fg, rows_m, cols_n, vec_store);
+    else if (p.out_dtype == FP8MI_BF16) epilogue<C, FP8MI_BF16>(p, acc, m0, n0, wm0, wn0, fr, fg, rows_m, cols_n, vec_store);
+    else epilogue<C, FP8MI_F16>(p, acc, m0, n0, wm0, wn0, fr, fg, rows_m, cols_n, vec_store);
+#ifdef FP8MI_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(k2_);
+    if (threadIdx.x == 0 && blockIdx.x < 256) {
+        g_stamp[blockIdx.x * 8 + 5] = k1_ - k0_;   // entry .. end of K loop (incl. NaN check)
+        g_stamp[blockIdx.x * 8 + 6] = k2_ - k1_;   // epilogue incl. store drain
     }
+#endif
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE>
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool PP = false>
 int launch(const MMParams &p, hipStream_t s)
 {
-    using C = Cfg<BM, BN, WM, WN, NSTAGE>;
+    using C = Cfg<BM, BN, WM, WN, NSTAGE, PP>;
     const int64_t tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     if (tm * tn > 0x7FFFFFFF) return FP8MI_E_UNSUPPORTED;
     const int esz = p.out_dtype == FP8MI_F32 ? 4 : 2;
     const int vec = ((p.ldc % 4) == 0 && (((uintptr_t)p.C) % (4 * esz)) == 0) ? 1 : 0;
-    FP8MI_LAUNCH((gemm_kernel<BM, BN, WM, WN, NSTAGE>), dim3((unsigned)(tm * tn)), dim3(C::kThreads), s, p, (int)tm,
+    FP8MI_LAUNCH((gemm_kernel<BM, BN, WM, WN, NSTAGE, PP>), dim3((unsigned)(tm * tn)), dim3(C::kThreads), s, p, (int)tm,
                        vec);
     return (int)hipGetLastError();
 }
 
 }  // namespace
+
+#ifdef FP8MI_STAMP
+extern "C" int fp8mi_debug_read_stamps(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * n);
+}
+#endif
 
 bool fp8mi_gemm_supported(const MMParams &p)
 {
@@ -341,9 +539,18 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
         else variant = FP8MI_KERNEL_GEMM_128x64;
     }
     switch (variant) {
-    case FP8MI_KERNEL_GEMM_128: return launch<128, 128, 64, 64, 4>(p, s);     // 4 x 32 KiB ring
-    case FP8MI_KERNEL_GEMM_128x64: return launch<128, 64, 64, 32, 6>(p, s);    // 6 x 24 KiB ring
-    case FP8MI_KERNEL_GEMM_256: return launch<256, 256, 128, 64, 2>(p, s);     // 2 x 64 KiB
+    case FP8MI_KERNEL_GEMM_128: return launch<128, 128, 64, 64, 4>(p, s);     // 4 waves, 4 x 32 KiB ring
+    case FP8MI_KERNEL_GEMM_128x64: return launch<128, 64, 64, 32, 6>(p, s);    // 4 waves, 6 x 24 KiB ring
+    case FP8MI_KERNEL_GEMM_256: return launch<256, 256, 128, 64, 2>(p, s);     // 8 waves, 2 x 64 KiB
+    case 7: return launch<128, 64, 32, 32, 6>(p, s);                           // 8 waves (2 per SIMD)
+    case 8: return launch<128, 128, 64, 32, 4>(p, s);                          // 8 waves
+    case 9: return launch<256, 128, 64, 64, 3>(p, s);                          // 8 waves, 3 x 48 KiB ring
+    case 10: return launch<128, 64, 32, 32, 3>(p, s);                          // 8 waves, 72 KiB: 2 blocks / CU
+    case 11: return launch<128, 128, 64, 32, 2>(p, s);                         // 8 waves, 64 KiB: 2 blocks / CU
+    case 12: return launch<256, 256, 128, 64, 2, true>(p, s);                  // ping-pong, 2 x 64 KiB
+    case 13: return launch<128, 64, 32, 32, 6, true>(p, s);                    // ping-pong, 6 x 24 KiB
+    case 14: return launch<128, 128, 64, 32, 4, true>(p, s);                   // ping-pong, 4 x 32 KiB
+    case 15: return launch<256, 128, 64, 64, 3, true>(p, s);                   // ping-pong, 3 x 48 KiB
     default: return FP8MI_E_ENUM;
     }
 }

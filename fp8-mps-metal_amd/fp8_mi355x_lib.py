@@ -22,7 +22,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfp8mi.so")
+# FP8MI_LIB_PATH lets a diagnostic build (e.g. libfp8mi_stamp.so) stand in; default is the product library
+LIB_PATH = os.environ.get("FP8MI_LIB_PATH") or os.path.join(_HERE, "libfp8mi.so")
 
 # enums of include/fp8mi.h
 F32, F16, BF16 = 0, 1, 2

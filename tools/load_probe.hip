@@ -1,0 +1,88 @@
+// Probe: per-CU cost of moving L2-resident bytes on-chip, LDS-DMA vs register loads.
+//   hipcc --offload-arch=gfx950 -O3 tools/load_probe.hip -o tools/load_probe && tools/load_probe
+// One workgroup per CU (256 blocks), W waves each, every wave issues R x 1 KiB
+// loads per round from a small (L2-resident) buffer, ROUNDS rounds.  Reports
+// cycles per wave-instruction and GB/s per CU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <vector>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int MODE, int R>  // 0: buffer_load ... lds, 1: global_load_dwordx4 -> VGPR (+xor sink), 2: VGPR + ds_write_b128
+__global__ __launch_bounds__(1024) void k(const uint8_t *src, uint32_t *sink, unsigned long long *cyc, int rounds, int span)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t smem[64 * 1024];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, span, 0x00020000);
+    uint32_t acc = 0;
+    __syncthreads();
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    uint32_t off = (uint32_t)((blockIdx.x * 7919u + wave * 131u) * 1024u);
+    for (int r = 0; r < rounds; ++r) {
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                uint32_t o = (off + j * 1024u * nw + lane * 16u) % (uint32_t)span;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(smem + ((wave * R + j) % 64) * 1024), 16, (int)o, 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            u32x4 v[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                uint32_t o = (off + j * 1024u * nw + lane * 16u) % (uint32_t)span;
+                v[j] = *(const u32x4 *)(src + o);
+            }
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                if (MODE == 1) acc ^= v[j][0] ^ v[j][1] ^ v[j][2] ^ v[j][3];
+                else *(u32x4 *)(smem + ((wave * R + j) % 64) * 1024 + lane * 16) = v[j];
+            }
+        }
+        off += 1024u * nw * R;
+    }
+    if (MODE == 2) { __syncthreads(); acc = *(uint32_t *)(smem + threadIdx.x * 4); }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+template <int MODE, int R>
+void run(const char *name, int waves, const uint8_t *src, uint32_t *sink, unsigned long long *cyc, int span)
+{
+    const int rounds = 200;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k<MODE, R>), 256, waves * 64, 0, 0, src, sink, cyc, 20, span);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k<MODE, R>), 256, waves * 64, 0, 0, src, sink, cyc, rounds, span);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(256);
+    hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost);
+    double avg = 0; for (auto c : h) avg += c; avg /= 256;
+    double instr_per_wave = (double)rounds * R;
+    double bytes_cu = instr_per_wave * waves * 1024.0;
+    printf("%-26s waves/CU %2d  R %2d: %7.1f cyc per wave-instr, %6.1f GB/s per CU (%5.2f TB/s chip), kernel %.1f us\n", name, waves, R,
+           avg / instr_per_wave, bytes_cu / (ms * 1e-3) / 1e9, bytes_cu * 256 / (ms * 1e-3) / 1e12, ms * 1e3);
+}
+
+int main()
+{
+    const int span = 2 << 20;  // 2 MiB: L2-resident per XCD
+    uint8_t *src; uint32_t *sink; unsigned long long *cyc;
+    hipMalloc(&src, span + 65536); hipMemset(src, 1, span + 65536); hipMalloc(&sink, 4); hipMalloc(&cyc, 256 * 8);
+    for (int w : {1, 2, 4, 8, 16}) {
+        run<0, 6>("LDS-DMA (buffer_load lds)", w, src, sink, cyc, span);
+        run<1, 6>("global_load_dwordx4->VGPR", w, src, sink, cyc, span);
+        run<2, 6>("VGPR + ds_write_b128", w, src, sink, cyc, span);
+    }
+    for (int w : {4, 8}) {
+        run<0, 16>("LDS-DMA (buffer_load lds)", w, src, sink, cyc, span);
+        run<1, 16>("global_load_dwordx4->VGPR", w, src, sink, cyc, span);
+        run<2, 16>("VGPR + ds_write_b128", w, src, sink, cyc, span);
+    }
+    return 0;
+}

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of the GEMM K loop (needs libfp8mi_stamp.so).
+    FP8MI_LIB_PATH=fp8-mps-metal_amd/libfp8mi_stamp.so python tools/stamp_gemm.py <gemm|flux> <kernel_id>"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch, bench
+import fp8_mi355x_lib as L
+name, kernel = sys.argv[1], int(sys.argv[2])
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+w = bench.Workload(name, dev, kernel=kernel)
+s = torch.cuda.current_stream(dev).cuda_stream
+for i in range(4): w.launch(i, s)
+torch.cuda.synchronize()
+lib = L.load()
+buf = (ctypes.c_ulonglong * (256 * 8))()
+lib.fp8mi_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+assert lib.fp8mi_debug_read_stamps(buf, 256 * 8) == 0
+import numpy as np
+a = np.array(list(buf), dtype=np.float64).reshape(256, 8)
+nk = a[:, 4].max()
+print(f"{name} kernel {kernel}: nk={int(nk)}; mean cycles per K-step over 256 blocks (wave 0):")
+for i, n in enumerate(("wait(vmcnt)", "barrier", "issue loads", "ds_read+MFMA")):
+    print(f"  {n:14s} {a[:, i].mean() / nk:8.1f}   (min {a[:, i].min() / nk:7.1f}, max {a[:, i].max() / nk:7.1f})")
+print(f"  total          {a[:, :4].sum(1).mean() / nk:8.1f}")
+print(f"per tile (wave 0): entry->end of K loop {a[:, 5].mean():9.0f} ticks (loop body {a[:, :4].sum(1).mean():9.0f}), epilogue+store drain {a[:, 6].mean():9.0f} ticks")
