@@ -403,6 +403,76 @@ FP8MI_DEVICE void epilogue(const MMParams &p, const f32x4 (&acc)[C::TN][C::TM], 
     }
 }
 
+// Epilogue for FULL tiles: same arithmetic, but each wave transposes its output
+// through a private corner of the (now idle) LDS ring so that every global store
+// instruction writes whole 128-byte lines (8 rows x 128 B for 16-bit outputs,
+// 4 rows x 256 B for fp32) instead of 16 scattered 32- / 64-byte pieces - the
+// direct form was store-issue bound (22k of 112k cycles per 256x256 bf16 tile).
+template <typename C, int OUT>
+FP8MI_DEVICE void epilogue_staged(const MMParams &p, const f32x4 (&acc)[C::TN][C::TM], uint8_t *smem, int64_t m0,
+                                  int64_t n0, int wave, int wm0, int wn0, int lane)
+{
+    constexpr int kEsz = OUT == FP8MI_F32 ? 4 : 2;
+    constexpr int WNc = C::TN * 16;              // columns of the wave tile
+    constexpr int kRowBytes = WNc * kEsz;        // 64 .. 256
+    constexpr int kStride = kRowBytes + 16;      // padded: spreads the 16 rows over the banks
+    constexpr int kCPR = kRowBytes / 16;         // 16-byte chunks per row
+    constexpr int kRPI = 64 / kCPR;              // rows written per store instruction
+    constexpr int kNI = 16 / kRPI;               // store instructions per 16-row fragment
+    static_assert(C::kWaves * 16 * kStride <= C::NSTAGE * C::kStageBytes, "staging fits in the ring");
+    uint8_t *buf = smem + wave * (16 * kStride);
+    const int fr = lane & 15, fg = lane >> 4;
+
+    const bool has_bias = p.bias != nullptr, has_sr = p.scale_result != nullptr;
+    const float sr = has_sr ? p.scale_result[0] : 1.0f;
+    float sbv[C::TN][4], bv[C::TN][4];
+    const float sb0 = p.scale_b[0], sa0 = p.scale_a[0];
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t n = n0 + wn0 + tn * 16 + fg * 4 + j;
+            sbv[tn][j] = p.sb_row ? p.scale_b[n] : sb0;
+            bv[tn][j] = has_bias ? load_as_float(p.bias, n, p.bias_dtype) : 0.0f;
+        }
+    const int rrow = lane / kCPR, rchunk = lane % kCPR;  // this lane's (row, 16-byte chunk) when reading back
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm) {
+        const float sa = p.sa_row ? p.scale_a[m0 + wm0 + tm * 16 + fr] : sa0;
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float r = (acc[tn][tm][j] * sa) * sbv[tn][j];
+                if (has_bias) r = r + bv[tn][j];
+                if (has_sr) r = r * sr;
+                v[j] = r;
+            }
+            uint8_t *d = buf + fr * kStride + (tn * 16 + fg * 4) * kEsz;
+            if (OUT == FP8MI_F32) {
+                *(f32x4 *)d = f32x4{v[0], v[1], v[2], v[3]};
+            } else if (OUT == FP8MI_BF16) {
+                __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1], h2 = (__bf16)v[2], h3 = (__bf16)v[3];
+                *(u32x2 *)d = u32x2{(uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16),
+                                    (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16)};
+            } else {
+                _Float16 h0 = (_Float16)v[0], h1 = (_Float16)v[1], h2 = (_Float16)v[2], h3 = (_Float16)v[3];
+                *(u32x2 *)d = u32x2{(uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16),
+                                    (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16)};
+            }
+        }
+        // same wave wrote and reads: DS operations of one wave execute in order
+        uint8_t *grow = (uint8_t *)p.C + ((m0 + wm0 + tm * 16) * p.ldc + n0 + wn0) * kEsz;
+#pragma unroll
+        for (int i = 0; i < kNI; ++i) {
+            const int r = i * kRPI + rrow;
+            u32x4 q = *(const u32x4 *)(buf + r * kStride + rchunk * 16);
+            *(u32x4 *)(grow + (int64_t)r * p.ldc * kEsz + rchunk * 16) = q;
+        }
+    }
+}
+
 template <typename C, bool SCRUB>
 FP8MI_DEVICE void run_tile_any(const MMParams &p, uint8_t *smem, const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra,
                                __amdgpu_buffer_rsrc_t rb, int wave, int wm0, int wn0, uint32_t off1, uint32_t off2,
@@ -488,7 +558,11 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP>::kThreads)) void g
     STAMP(k1_);
     // ---- fused epilogue ---------------------------------------------------
     const int rows_m = (int)rows_a, cols_n = (int)rows_b;  // valid extent of this tile
-    if (p.out_dtype == FP8MI_F32) epilogue<C, FP8MI_F32>(p, acc, m0, n0, wm0, wn0, fr, fg, rows_m, cols_n, vec_store);
+    if (rows_m == BM && cols_n == BN && vec_store) {  // interior tile, 16-byte aligned rows: line-coalesced stores
+        if (p.out_dtype == FP8MI_F32) epilogue_staged<C, FP8MI_F32>(p, acc, smem, m0, n0, wave, wm0, wn0, lane);
+        else if (p.out_dtype == FP8MI_BF16) epilogue_staged<C, FP8MI_BF16>(p, acc, smem, m0, n0, wave, wm0, wn0, lane);
+        else epilogue_staged<C, FP8MI_F16>(p, acc, smem, m0, n0, wave, wm0, wn0, lane);
+    } else if (p.out_dtype == FP8MI_F32) epilogue<C, FP8MI_F32>(p, acc, m0, n0, wm0, wn0, fr, fg, rows_m, cols_n, vec_store);
     else if (p.out_dtype == FP8MI_BF16) epilogue<C, FP8MI_BF16>(p, acc, m0, n0, wm0, wn0, fr, fg, rows_m, cols_n, vec_store);
     else epilogue<C, FP8MI_F16>(p, acc, m0, n0, wm0, wn0, fr, fg, rows_m, cols_n, vec_store);
 #ifdef FP8MI_STAMP
@@ -508,7 +582,8 @@ int launch(const MMParams &p, hipStream_t s)
     const int64_t tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     if (tm * tn > 0x7FFFFFFF) return FP8MI_E_UNSUPPORTED;
     const int esz = p.out_dtype == FP8MI_F32 ? 4 : 2;
-    const int vec = ((p.ldc % 4) == 0 && (((uintptr_t)p.C) % (4 * esz)) == 0) ? 1 : 0;
+    // 16-byte aligned rows and 4-element groups: enables the vector stores of both epilogues
+    const int vec = (((p.ldc * esz) % 16) == 0 && (((uintptr_t)p.C) % 16) == 0) ? 1 : 0;
     FP8MI_LAUNCH((gemm_kernel<BM, BN, WM, WN, NSTAGE, PP>), dim3((unsigned)(tm * tn)), dim3(C::kThreads), s, p, (int)tm,
                        vec);
     return (int)hipGetLastError();
