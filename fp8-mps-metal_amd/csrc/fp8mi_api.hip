@@ -4,6 +4,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -144,29 +145,33 @@ int fp8mi_scaled_mm_ex(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     p.sa_row = scale_a_mode; p.sb_row = scale_b_mode;
     p.out_dtype = out_dtype; p.bias_dtype = bias_dtype;
     p.nan_zero = nan_mode == FP8MI_NAN_ZERO;
+    p.debug = 0;
     hipStream_t s = (hipStream_t)stream;
 
     switch (kernel) {
     case FP8MI_KERNEL_AUTO:
         if (fp8mi_gemv_supported(p)) return hip_result(fp8mi_launch_gemv(p, s), "gemv");
-        if (fp8mi_skinny_supported(p)) return hip_result(fp8mi_launch_skinny(p, s), "skinny");
+        if (p.M >= 2 && p.M <= 32 && fp8mi_skinny_supported(p)) return hip_result(fp8mi_launch_skinny(p, s), "skinny");
         if (K > 0 && fp8mi_gemm_supported(p)) return hip_result(fp8mi_launch_gemm(p, FP8MI_KERNEL_AUTO, s), "gemm");
         return hip_result(fp8mi_launch_generic(p, s), "generic");
     case FP8MI_KERNEL_GEMV:
         if (!fp8mi_gemv_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "gemv kernel needs M == 1, K %% 16 == 0, 16-byte aligned rows");
         return hip_result(fp8mi_launch_gemv(p, s), "gemv");
     case FP8MI_KERNEL_SKINNY:
-        if (!fp8mi_skinny_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "skinny kernel needs 1 <= M <= 16, K %% 16 == 0, 16-byte aligned rows");
+        if (!fp8mi_skinny_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "skinny kernel needs 1 <= M <= 64, K %% 16 == 0, 16-byte aligned rows");
         return hip_result(fp8mi_launch_skinny(p, s), "skinny");
     case FP8MI_KERNEL_GEMM_128:
     case FP8MI_KERNEL_GEMM_128x64:
     case FP8MI_KERNEL_GEMM_256:
-    case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15:  // experimental tile / wave-count variants
+    case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25: case 26:  // experimental tile / wave-count variants
         if (!fp8mi_gemm_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "MFMA gemm kernel needs K %% 16 == 0 and 16-byte aligned rows");
         return hip_result(fp8mi_launch_gemm(p, kernel, s), "gemm");
     case FP8MI_KERNEL_GENERIC:
         return hip_result(fp8mi_launch_generic(p, s), "generic");
     default:
+#ifdef FP8MI_ABLATE
+        if (kernel >= 100 && kernel < 120 && fp8mi_gemm_supported(p)) return hip_result(fp8mi_launch_gemm(p, kernel, s), "gemm-ablate");
+#endif
         return fail(FP8MI_E_ENUM, "fp8mi_scaled_mm_ex: unknown kernel id %d", kernel);
     }
 }

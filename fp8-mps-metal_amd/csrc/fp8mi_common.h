@@ -34,6 +34,7 @@ struct MMParams {
     int sa_row, sb_row;    // 0 per-tensor, 1 per-row
     int out_dtype, bias_dtype;
     int nan_zero;          // 1: NaN bytes decode to 0 (reference), 0: propagate
+    int debug;             // diagnostic builds only (FP8MI_STAMP): ablation bits, else 0
 };
 
 // SWAR scrub: zero every byte of w whose low 7 bits are all ones (the two

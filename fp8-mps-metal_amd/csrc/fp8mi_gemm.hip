@@ -55,9 +55,13 @@ constexpr int kScaleOne = 0x7F7F7F7F;  // E8M0 127 = 2^0 in every byte
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int BM, int BN, int WM, int WN, int NSTAGE_, bool PINGPONG_ = false>
+template <int BM, int BN, int WM, int WN, int NSTAGE_, int MODE_ = 0, int ABL_ = 0>
 struct Cfg {
-    static constexpr bool PINGPONG = PINGPONG_;
+    static constexpr int ABL = ABL_;    // timing-only ablation bits (diagnostic library only; 0 in the product)
+    static constexpr int MODE = MODE_;  // 0 plain ring loop, 1 ping-pong, 2 software-pipelined
+    static constexpr bool PINGPONG = MODE_ == 1;
+    static constexpr int TMS = (WM / 16) >= 2 ? 2 : 1;       // X fragments per register window
+    static constexpr int SUBS = (WM / 16) / TMS;             // sub-steps per K-step
     static constexpr int NSTAGE = NSTAGE_;
     static constexpr int PF = NSTAGE_ - 1;  // K-steps of loads in flight
     static constexpr int kWavesM = BM / WM;
@@ -72,9 +76,9 @@ struct Cfg {
     static constexpr int kGroupsPerWave = kGroups / kWaves;
     static constexpr int kStageBytes = (BM + BN) * BK;
     static_assert(kGroups % kWaves == 0, "staging groups must divide evenly over the waves");
-    static_assert(NSTAGE_ >= 2 && (NSTAGE_ - 2) * kGroupsPerWave <= 63, "vmcnt is a 6-bit counter");
+    static_assert(NSTAGE_ >= 2 && NSTAGE_ <= 6 && (NSTAGE_ - 1) * kGroupsPerWave <= 63, "vmcnt is a 6-bit counter");
     static_assert(NSTAGE_ * kStageBytes <= 160 * 1024, "LDS is 160 KiB per CU");
-    static_assert(!PINGPONG_ || kWaves == 8, "the ping-pong schedule pairs waves w and w + 4 on one SIMD");
+    static_assert(MODE_ != 1 || kWaves == 8, "the ping-pong schedule pairs waves w and w + 4 on one SIMD");
 };
 
 // one K-step's fragments: LDS -> registers
@@ -120,6 +124,33 @@ FP8MI_DEVICE void mfma_all(const i32x8 (&xf)[C::TM], const i32x8 (&wf)[C::TN], f
                                                                             kScaleOne, 0, kScaleOne);
 }
 
+// ---- pieces of a K-step for the software-pipelined loop ---------------------
+template <typename C, bool SCRUB, int N>
+FP8MI_DEVICE void read_frags(const uint8_t *rows, uint32_t off1, uint32_t off2, i32x8 (&f)[N])
+{
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        i32x4 lo = *(const i32x4 *)(rows + t * 16 * BK + off1);
+        i32x4 hi = *(const i32x4 *)(rows + t * 16 * BK + off2);
+        f[t] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (SCRUB) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[t][j] = (int)scrub_nan4((uint32_t)f[t][j]);
+        }
+    }
+}
+
+template <typename C, int TMS>
+FP8MI_DEVICE void mfma_window(const i32x8 (&xw)[TMS], const i32x8 (&wf)[C::TN], f32x4 (&acc)[C::TN][C::TM], int tm0)
+{
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+        for (int i = 0; i < TMS; ++i)
+            acc[tn][tm0 + i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[tn], xw[i], acc[tn][tm0 + i], 0, 0, 0,
+                                                                                kScaleOne, 0, kScaleOne);
+}
+
 template <typename C, bool SCRUB>
 FP8MI_DEVICE void compute_step(const uint8_t *stage, int a_row0, int b_row0, uint32_t off1, uint32_t off2,
                                f32x4 (&acc)[C::TN][C::TM])
@@ -134,6 +165,21 @@ struct StagePlan {
     uint32_t voff[C::kGroupsPerWave];  // per-lane byte offset inside the operand's buffer, or kOOB
     uint32_t kpos[C::kGroupsPerWave];  // chunk*16: position of this lane's 16 bytes inside the K-step
 };
+
+// one staging group (1 KiB for this wave); `null` points every lane outside the
+// buffer: a DMA that only writes zeros - used to keep the issue unconditional
+// (and the per-stage vmcnt bookkeeping uniform) past the last K-step
+template <typename C>
+FP8MI_DEVICE void issue_group(const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, uint8_t *stage,
+                              int wave, int j, int k0, int64_t K, bool null)
+{
+    const int gi = wave + j * C::kWaves;
+    uint32_t vo = pl.voff[j];
+    if (null || (int64_t)k0 + pl.kpos[j] >= K) vo = kOOB;
+    lds_void *dst = (lds_void *)(stage + gi * 1024);
+    if (gi < C::kGroupsA) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, (int)vo, k0, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, (int)vo, k0, 0, 0);
+}
 
 template <typename C, bool TAIL>
 FP8MI_DEVICE void issue_stage(const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
@@ -174,14 +220,17 @@ FP8MI_DEVICE void wait_loads_and_lds()
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
+// wait until at most `newer_stages` stages' worth of this wave's LDS-DMA is outstanding
+// (loads retire in issue order, so the older stage has landed), and its ds_reads are done
 template <typename C>
 FP8MI_DEVICE void wait_stage(int newer_stages)
 {
     constexpr int G = C::kGroupsPerWave;
-    if (C::PF >= 2 && newer_stages >= C::PF - 1) wait_loads_and_lds<(C::PF - 1) * G>();
-    else if (C::PF >= 5 && newer_stages == 3) wait_loads_and_lds<3 * G>();
-    else if (C::PF >= 4 && newer_stages == 2) wait_loads_and_lds<2 * G>();
-    else if (C::PF >= 3 && newer_stages == 1) wait_loads_and_lds<1 * G>();
+    if (5 * G <= 63 && newer_stages >= 5) wait_loads_and_lds<(5 * G <= 63 ? 5 * G : 0)>();
+    else if (4 * G <= 63 && newer_stages == 4) wait_loads_and_lds<(4 * G <= 63 ? 4 * G : 0)>();
+    else if (3 * G <= 63 && newer_stages == 3) wait_loads_and_lds<(3 * G <= 63 ? 3 * G : 0)>();
+    else if (2 * G <= 63 && newer_stages == 2) wait_loads_and_lds<(2 * G <= 63 ? 2 * G : 0)>();
+    else if (newer_stages == 1) wait_loads_and_lds<G>();
     else wait_loads_and_lds<0>();
 }
 
@@ -232,9 +281,29 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
         STAMP(s1);
         __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave is done reading slot of step t-1
         STAMP(s2);
-        if (t + C::PF < nk) issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, next_ks(), nk, ktail, K);
+        if (!(C::ABL & 1)) {
+            if (t + C::PF < nk) issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, next_ks(), nk, ktail, K);
+        }
         STAMP(s3);
-        compute_step<C, SCRUB>(smem + slot * C::kStageBytes, wm0, wn0, off1, off2, acc);
+        if constexpr (C::ABL == 0) {
+            compute_step<C, SCRUB>(smem + slot * C::kStageBytes, wm0, wn0, off1, off2, acc);
+        } else {  // timing-only ablations (diagnostic library): 1 no LDS-DMA, 2 no ds_read, 4 no MFMA
+            i32x8 xf_[C::TM], wf_[C::TN];
+            if constexpr (!(C::ABL & 2)) load_frags<C, SCRUB>(smem + slot * C::kStageBytes, wm0, wn0, off1, off2, xf_, wf_);
+            else {
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i) xf_[i] = i32x8{t, t, t, t, t, t, t, t};
+#pragma unroll
+                for (int i = 0; i < C::TN; ++i) wf_[i] = i32x8{t, 1, t, 1, t, 1, t, 1};
+            }
+            if constexpr (!(C::ABL & 4)) mfma_all<C>(xf_, wf_, acc);
+            else {
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i) asm volatile("" ::"v"(xf_[i]));
+#pragma unroll
+                for (int i = 0; i < C::TN; ++i) asm volatile("" ::"v"(wf_[i]));
+            }
+        }
         STAMP(s4);
         c_wait += s1 - s0; c_bar += s2 - s1; c_issue += s3 - s2; c_comp += s4 - s3;
         slot = (slot + 1 == C::NSTAGE) ? 0 : slot + 1;
@@ -473,23 +542,172 @@ FP8MI_DEVICE void epilogue_staged(const MMParams &p, const f32x4 (&acc)[C::TN][C
     }
 }
 
+// Software-pipelined K loop.  Inside every wave the LDS reads and the LDS-DMA
+// issue for what comes NEXT run under the MFMAs of what is current:
+//   * the W fragments (TN x 8 VGPRs) are double-buffered across K-steps,
+//   * the X fragments stream through a 2-deep register window of TMS fragments
+//     (a K-step = SUBS sub-steps of TMS x TN MFMAs),
+//   * one barrier per K-step, placed before the LAST sub-step: by then every read
+//     of the current slot has been issued (and is waited for), so the slot is
+//     refilled right there with stage t + NSTAGE, and the first fragments of step
+//     t+1 are fetched under the last sub-step's MFMAs.
+// NSTAGE stages are in flight after the prologue, NSTAGE-1 at every wait.
+template <typename C, bool SCRUB, int PAR>
+FP8MI_DEVICE void swp_step(uint8_t *smem, const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
+                           int wave, int wm0, int wn0, uint32_t off1, uint32_t off2, int t, int nk, bool ktail, int64_t K,
+                           int &slot, int &ks, i32x8 (&wf)[2][C::TN], i32x8 (&xw)[2][C::TMS], f32x4 (&acc)[C::TN][C::TM])
+{
+    constexpr int SUBS = C::SUBS, TMS = C::TMS;
+    const uint8_t *cur = smem + slot * C::kStageBytes;
+    const int nslot = (slot + 1 == C::NSTAGE) ? 0 : slot + 1;
+    const uint8_t *nxt = smem + nslot * C::kStageBytes;
+    const uint8_t *xrows = cur + wm0 * BK;
+#pragma unroll
+    for (int q = 0; q < SUBS; ++q) {
+        constexpr int kDummy = 0; (void)kDummy;
+        const int wq = (q + (SUBS & 1) * PAR) & 1;  // window holding sub-step q's X fragments
+        if (q + 1 < SUBS) {
+            read_frags<C, SCRUB, TMS>(xrows + (q + 1) * TMS * 16 * BK, off1, off2, xw[wq ^ 1]);
+        } else {
+            // every read of `cur` is issued; wait for them and for stage t+1, then refill `cur`
+            if (t + 1 < nk) wait_stage<C>(min(C::NSTAGE - 2, nk - 2 - t));
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + C::NSTAGE < nk) {
+                issue_any<C>(pl, ra, rb, smem + slot * C::kStageBytes, wave, ks, nk, ktail, K);
+                ks = (ks + 1 == nk) ? 0 : ks + 1;
+            }
+            if (t + 1 < nk) {
+                read_frags<C, SCRUB, TMS>(nxt + wm0 * BK, off1, off2, xw[wq ^ 1]);
+                read_frags<C, SCRUB, C::TN>(nxt + (C::kGroupsA * 8 + wn0) * BK, off1, off2, wf[PAR ^ 1]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_window<C, TMS>(xw[wq], wf[PAR], acc, q * TMS);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    slot = nslot;
+}
+
+template <typename C, bool SCRUB>
+FP8MI_DEVICE void run_tile_swp(const MMParams &p, uint8_t *smem, const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra,
+                               __amdgpu_buffer_rsrc_t rb, int wave, int wm0, int wn0, uint32_t off1, uint32_t off2,
+                               int rot, f32x4 (&acc)[C::TN][C::TM])
+{
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm) acc[tn][tm] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int64_t K = p.K;
+    const int nk = (int)((K + BK - 1) / BK);
+    const bool ktail = (K % BK) != 0;
+    if (nk == 0) return;
+    int ks = rot;
+    // prologue: fill the whole ring
+#pragma unroll
+    for (int s = 0; s < C::NSTAGE; ++s)
+        if (s < nk) {
+            issue_any<C>(pl, ra, rb, smem + s * C::kStageBytes, wave, ks, nk, ktail, K);
+            ks = (ks + 1 == nk) ? 0 : ks + 1;
+        }
+    wait_stage<C>(min(C::NSTAGE - 1, nk - 1));  // stage 0
+    __builtin_amdgcn_s_barrier();
+    i32x8 wf[2][C::TN], xw[2][C::TMS];
+    read_frags<C, SCRUB, C::TMS>(smem + wm0 * BK, off1, off2, xw[0]);
+    read_frags<C, SCRUB, C::TN>(smem + (C::kGroupsA * 8 + wn0) * BK, off1, off2, wf[0]);
+    int slot = 0;
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+        swp_step<C, SCRUB, 0>(smem, pl, ra, rb, wave, wm0, wn0, off1, off2, t, nk, ktail, K, slot, ks, wf, xw, acc);
+        swp_step<C, SCRUB, 1>(smem, pl, ra, rb, wave, wm0, wn0, off1, off2, t + 1, nk, ktail, K, slot, ks, wf, xw, acc);
+    }
+    if (t < nk) swp_step<C, SCRUB, 0>(smem, pl, ra, rb, wave, wm0, wn0, off1, off2, t, nk, ktail, K, slot, ks, wf, xw, acc);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // ring idle: reusable by the NaN re-run / the staged epilogue
+}
+
+// Ring loop with the LDS-DMA issue INTERLEAVED into the MFMA stream: a wave that
+// issues its G loads back to back stalls in the address path (the CU takes ~16
+// cycles per 1-KiB instruction) before its first MFMA; here each group of
+// MFMAs is followed by one DMA issue, so the matrix pipe starts at once and the
+// loads trickle out underneath it.  The issue is unconditional (a null DMA past
+// the last K-step) so that it lives in the MFMAs' basic block.
+template <typename C, bool SCRUB>
+FP8MI_DEVICE void run_tile_interleaved(const MMParams &p, uint8_t *smem, const StagePlan<C> &pl,
+                                       __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int wave, int wm0, int wn0,
+                                       uint32_t off1, uint32_t off2, int rot, f32x4 (&acc)[C::TN][C::TM])
+{
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm) acc[tn][tm] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int64_t K = p.K;
+    const int nk = (int)((K + BK - 1) / BK);
+    if (nk == 0) return;
+    constexpr int G = C::kGroupsPerWave, NM = C::TM * C::TN;
+    constexpr int MPG = (NM + G - 1) / G;  // MFMAs per DMA issue
+    int ks = rot;
+    auto next_ks = [&]() { const int r = ks; ks = (ks + 1 == nk) ? 0 : ks + 1; return r; };
+#pragma unroll
+    for (int s = 0; s < C::PF; ++s) {
+        const bool null = s >= nk;
+        const int k0 = (null ? 0 : next_ks()) * BK;
+#pragma unroll
+        for (int j = 0; j < G; ++j) issue_group<C>(pl, ra, rb, smem + s * C::kStageBytes, wave, j, k0, K, null);
+    }
+    int slot = 0, fill = C::PF % C::NSTAGE;
+    for (int t = 0; t < nk; ++t) {
+        wait_loads_and_lds<(C::PF - 1) * G>();  // uniform count: null DMAs keep PF stages issued ahead at all times
+        __builtin_amdgcn_s_barrier();
+        const bool null = t + C::PF >= nk;
+        const int k0 = (null ? 0 : next_ks()) * BK;
+        uint8_t *dst = smem + fill * C::kStageBytes;
+        i32x8 xf[C::TM], wf[C::TN];
+        load_frags<C, SCRUB>(smem + slot * C::kStageBytes, wm0, wn0, off1, off2, xf, wf);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            const int tn = i / C::TM, tm = i % C::TM;
+            acc[tn][tm] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0, kScaleOne, 0,
+                                                                            kScaleOne);
+            if ((i + 1) % MPG == 0 && (i + 1) / MPG <= G) issue_group<C>(pl, ra, rb, dst, wave, (i + 1) / MPG - 1, k0, K, null);
+        }
+#pragma unroll
+        for (int j = NM / MPG; j < G; ++j) issue_group<C>(pl, ra, rb, dst, wave, j, k0, K, null);
+        // pin the emitted order: MPG MFMAs, then one DMA issue, G times
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read (the LDS-DMA)
+        }
+        slot = (slot + 1 == C::NSTAGE) ? 0 : slot + 1;
+        fill = (fill + 1 == C::NSTAGE) ? 0 : fill + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 template <typename C, bool SCRUB>
 FP8MI_DEVICE void run_tile_any(const MMParams &p, uint8_t *smem, const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra,
                                __amdgpu_buffer_rsrc_t rb, int wave, int wm0, int wn0, uint32_t off1, uint32_t off2,
                                int rot, f32x4 (&acc)[C::TN][C::TM])
 {
-    if constexpr (C::PINGPONG) run_tile_pingpong<C, SCRUB>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, rot, acc);
+    if constexpr (C::MODE == 1) run_tile_pingpong<C, SCRUB>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, rot, acc);
+    else if constexpr (C::MODE == 2) run_tile_swp<C, SCRUB>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, rot, acc);
+    else if constexpr (C::MODE == 3) run_tile_interleaved<C, SCRUB>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, rot, acc);
     else run_tile<C, SCRUB>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, rot, acc);
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool PP>
-__global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP>::kThreads)) void gemm_kernel(MMParams p, int tiles_m, int vec_store)
+template <int BM, int BN, int WM, int WN, int NSTAGE, int PP, int ABL>
+__global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL>::kThreads)) void gemm_kernel(MMParams p, int tiles_m, int vec_store)
 {
-    using C = Cfg<BM, BN, WM, WN, NSTAGE, PP>;
+    using C = Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL>;
     __shared__ __attribute__((aligned(16))) uint8_t smem[NSTAGE * C::kStageBytes];
 
     unsigned long long k0_ = 0, k1_ = 0, k2_ = 0; (void)k0_; (void)k1_; (void)k2_;
     STAMP(k0_);
+#ifdef FP8MI_STAMP
+    const unsigned long long r0_ = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- XCD-aware, bijective block -> tile map (m fastest) -------------
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
@@ -571,20 +789,21 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP>::kThreads)) void g
     if (threadIdx.x == 0 && blockIdx.x < 256) {
         g_stamp[blockIdx.x * 8 + 5] = k1_ - k0_;   // entry .. end of K loop (incl. NaN check)
         g_stamp[blockIdx.x * 8 + 6] = k2_ - k1_;   // epilogue incl. store drain
+        g_stamp[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime() - r0_;  // 100 MHz ticks over the whole tile
     }
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool PP = false>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int PP = 0, int ABL = 0>
 int launch(const MMParams &p, hipStream_t s)
 {
-    using C = Cfg<BM, BN, WM, WN, NSTAGE, PP>;
+    using C = Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL>;
     const int64_t tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     if (tm * tn > 0x7FFFFFFF) return FP8MI_E_UNSUPPORTED;
     const int esz = p.out_dtype == FP8MI_F32 ? 4 : 2;
     // 16-byte aligned rows and 4-element groups: enables the vector stores of both epilogues
     const int vec = (((p.ldc * esz) % 16) == 0 && (((uintptr_t)p.C) % 16) == 0) ? 1 : 0;
-    FP8MI_LAUNCH((gemm_kernel<BM, BN, WM, WN, NSTAGE, PP>), dim3((unsigned)(tm * tn)), dim3(C::kThreads), s, p, (int)tm,
+    FP8MI_LAUNCH((gemm_kernel<BM, BN, WM, WN, NSTAGE, PP, ABL>), dim3((unsigned)(tm * tn)), dim3(C::kThreads), s, p, (int)tm,
                        vec);
     return (int)hipGetLastError();
 }
@@ -607,6 +826,9 @@ bool fp8mi_gemm_supported(const MMParams &p)
 int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
 {
     if (variant == FP8MI_KERNEL_AUTO) {
+        // measured on MI355X: 256x256 once it fills ~3/4 of the CUs; otherwise 128x128
+        // with 8 waves and a 2-stage ring (two co-resident workgroups per CU hide each other's
+        // prologue / epilogue); below that the 128x64 / 8-wave / 6-stage variant (one tile per CU)
         const int64_t t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
         const int64_t t128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
         if (t256 >= 192) variant = FP8MI_KERNEL_GEMM_256;
@@ -614,18 +836,45 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
         else variant = FP8MI_KERNEL_GEMM_128x64;
     }
     switch (variant) {
-    case FP8MI_KERNEL_GEMM_128: return launch<128, 128, 64, 64, 4>(p, s);     // 4 waves, 4 x 32 KiB ring
-    case FP8MI_KERNEL_GEMM_128x64: return launch<128, 64, 64, 32, 6>(p, s);    // 4 waves, 6 x 24 KiB ring
+    case FP8MI_KERNEL_GEMM_128: return launch<128, 128, 64, 32, 2>(p, s);     // 8 waves, 2 x 32 KiB: 2 workgroups / CU
+    case FP8MI_KERNEL_GEMM_128x64: return launch<128, 64, 32, 32, 6>(p, s);    // 8 waves, 6 x 24 KiB ring
+    case 2002: return launch<128, 128, 64, 64, 4>(p, s);                       // (4 waves, 4 x 32 KiB ring)
+    case 2005: return launch<128, 64, 64, 32, 6>(p, s);                        // (4 waves, 6 x 24 KiB ring)
     case FP8MI_KERNEL_GEMM_256: return launch<256, 256, 128, 64, 2>(p, s);     // 8 waves, 2 x 64 KiB
     case 7: return launch<128, 64, 32, 32, 6>(p, s);                           // 8 waves (2 per SIMD)
     case 8: return launch<128, 128, 64, 32, 4>(p, s);                          // 8 waves
     case 9: return launch<256, 128, 64, 64, 3>(p, s);                          // 8 waves, 3 x 48 KiB ring
     case 10: return launch<128, 64, 32, 32, 3>(p, s);                          // 8 waves, 72 KiB: 2 blocks / CU
     case 11: return launch<128, 128, 64, 32, 2>(p, s);                         // 8 waves, 64 KiB: 2 blocks / CU
-    case 12: return launch<256, 256, 128, 64, 2, true>(p, s);                  // ping-pong, 2 x 64 KiB
-    case 13: return launch<128, 64, 32, 32, 6, true>(p, s);                    // ping-pong, 6 x 24 KiB
-    case 14: return launch<128, 128, 64, 32, 4, true>(p, s);                   // ping-pong, 4 x 32 KiB
-    case 15: return launch<256, 128, 64, 64, 3, true>(p, s);                   // ping-pong, 3 x 48 KiB
+    case 12: return launch<256, 256, 128, 64, 2, 1>(p, s);                  // ping-pong, 2 x 64 KiB
+    case 13: return launch<128, 64, 32, 32, 6, 1>(p, s);                    // ping-pong, 6 x 24 KiB
+    case 14: return launch<128, 128, 64, 32, 4, 1>(p, s);                   // ping-pong, 4 x 32 KiB
+    case 15: return launch<256, 128, 64, 64, 3, 1>(p, s);                   // ping-pong, 3 x 48 KiB
+    case 16: return launch<256, 256, 128, 64, 2, 2>(p, s);                     // software-pipelined
+    case 17: return launch<128, 64, 64, 32, 6, 2>(p, s);                       // swp, 4 waves
+    case 18: return launch<128, 64, 32, 32, 6, 2>(p, s);                       // swp, 8 waves
+    case 19: return launch<128, 128, 64, 64, 4, 2>(p, s);                      // swp, 4 waves
+    case 20: return launch<256, 128, 64, 64, 3, 2>(p, s);                      // swp, 8 waves
+    case 21: return launch<128, 128, 64, 32, 4, 2>(p, s);                      // swp, 8 waves
+    case 22: return launch<256, 256, 128, 64, 2, 3>(p, s);                     // interleaved issue
+    case 23: return launch<128, 64, 32, 32, 6, 3>(p, s);                       // interleaved, 8 waves
+    case 24: return launch<128, 64, 64, 32, 6, 3>(p, s);                       // interleaved, 4 waves
+    case 25: return launch<256, 128, 64, 64, 3, 3>(p, s);                      // interleaved
+    case 26: return launch<128, 128, 64, 32, 4, 3>(p, s);                      // interleaved, 8 waves
+#ifdef FP8MI_ABLATE  // diagnostic library only: 10x = 128x64 8-wave, 11x = 256x256; x = ablation bits
+    case 101: return launch<128, 64, 32, 32, 6, 0, 1>(p, s);
+    case 102: return launch<128, 64, 32, 32, 6, 0, 2>(p, s);
+    case 104: return launch<128, 64, 32, 32, 6, 0, 4>(p, s);
+    case 103: return launch<128, 64, 32, 32, 6, 0, 3>(p, s);
+    case 105: return launch<128, 64, 32, 32, 6, 0, 5>(p, s);
+    case 106: return launch<128, 64, 32, 32, 6, 0, 6>(p, s);
+    case 111: return launch<256, 256, 128, 64, 2, 0, 1>(p, s);
+    case 112: return launch<256, 256, 128, 64, 2, 0, 2>(p, s);
+    case 114: return launch<256, 256, 128, 64, 2, 0, 4>(p, s);
+    case 113: return launch<256, 256, 128, 64, 2, 0, 3>(p, s);
+    case 115: return launch<256, 256, 128, 64, 2, 0, 5>(p, s);
+    case 116: return launch<256, 256, 128, 64, 2, 0, 6>(p, s);
+#endif
     default: return FP8MI_E_ENUM;
     }
 }

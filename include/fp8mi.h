@@ -57,11 +57,13 @@ enum { FP8MI_ENC_REFERENCE = 0,  /* fp8_matmul.metal:44-92 (see header comment) 
 /* kernel selection for fp8mi_scaled_mm_ex (testing / benchmarking) */
 enum { FP8MI_KERNEL_AUTO = 0,
        FP8MI_KERNEL_GEMV = 1,      /* M == 1 wavefront-reduced vec-mat                */
-       FP8MI_KERNEL_GEMM_128 = 2,  /* 128x128x128 LDS-tiled fp8 MFMA                  */
+       FP8MI_KERNEL_GEMM_128 = 2,  /* 128x128x128 LDS-tiled fp8 MFMA (mid sizes)      */
        FP8MI_KERNEL_GENERIC = 3,   /* any shape / alignment, one wave per output      */
        FP8MI_KERNEL_GEMM_256 = 4,  /* 256x256x128 LDS-tiled fp8 MFMA (large M,N)      */
-       FP8MI_KERNEL_GEMM_128x64 = 5,
-       FP8MI_KERNEL_SKINNY = 6 };  /* 2 <= M <= 16 weight-streaming MFMA              */
+       FP8MI_KERNEL_GEMM_128x64 = 5, /* 128x64x128 tile (few tiles: one per CU)       */
+       FP8MI_KERNEL_SKINNY = 6 };  /* 1 <= M <= 64 weight-streaming MFMA              */
+/* ids >= 7 select experimental schedule variants of the tile kernel (see
+ * fp8mi_gemm.hip); they compute the same result and exist for A/B timing. */
 
 /* error codes (negative returns) */
 enum { FP8MI_OK = 0,

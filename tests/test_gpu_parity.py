@@ -48,7 +48,7 @@ def clean_bytes(rng, shape):
 
 
 def uses_mfma(kernel, M, K):
-    if kernel in (L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256):
+    if kernel in (L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256, L.KERNEL_SKINNY):
         return True
     return kernel == L.KERNEL_AUTO and M > 1 and K % 16 == 0 and K > 0
 
@@ -252,6 +252,8 @@ def _kernels_for(M, K):
         ks += [L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256]
         if M == 1:
             ks.append(L.KERNEL_GEMV)
+        if M <= 64:
+            ks.append(L.KERNEL_SKINNY)
     return ks
 
 
@@ -319,6 +321,24 @@ def test_gemm_tile_kernels_ragged(native, cuda, oracle, kernel, M, K, N):
     sb = rng.uniform(0.005, 0.02, size=N).astype(np.float32)
     check_mm(oracle, native, cuda, A, B, sa, sb, kernel=kernel)
     check_mm(oracle, native, cuda, A, B, [0.01], sb, kernel=kernel)  # mixed per-tensor / per-row broadcasts
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 128, 16), (2, 16, 1), (4, 4096, 4096), (4, 1040, 100), (16, 4096, 512), (17, 528, 33),
+                                   (33, 2048, 200), (64, 14336, 256), (48, 144, 17)])
+def test_skinny_kernel(native, cuda, oracle, M, K, N):
+    """2 <= M <= 64 weight-streaming MFMA kernel (the reference's M <= 16 route,
+    fp8_mps_native.py:208; M=4, K=N=4096 is one of its published shapes, README.md:77),
+    NaN bytes included (scrubbed in-register)."""
+    rng = np.random.default_rng(M * 11 + K + N)
+    A = rng.integers(0, 256, size=(M, K), dtype=np.uint8)
+    B = rng.integers(0, 256, size=(N, K), dtype=np.uint8)
+    sa = rng.uniform(0.005, 0.02, size=M).astype(np.float32)
+    sb = rng.uniform(0.005, 0.02, size=N).astype(np.float32)
+    check_mm(oracle, native, cuda, A, B, sa, sb, kernel=L.KERNEL_SKINNY)
+    bias = rng.standard_normal(N).astype(np.float32)
+    check_mm(oracle, native, cuda, A, B, [0.01], sb, kernel=L.KERNEL_SKINNY, bias=bias, scale_result=0.5, out_dtype=torch.bfloat16)
+    if M >= 2:
+        check_mm(oracle, native, cuda, A, B, sa, [0.02])  # auto dispatch lands here for 2 <= M <= 32
 
 
 def test_gemm_mfma_operand_map_asymmetric(native, cuda, oracle):

@@ -23,4 +23,6 @@ print(f"{name} kernel {kernel}: nk={int(nk)}; mean cycles per K-step over 256 bl
 for i, n in enumerate(("wait(vmcnt)", "barrier", "issue loads", "ds_read+MFMA")):
     print(f"  {n:14s} {a[:, i].mean() / nk:8.1f}   (min {a[:, i].min() / nk:7.1f}, max {a[:, i].max() / nk:7.1f})")
 print(f"  total          {a[:, :4].sum(1).mean() / nk:8.1f}")
+tot = a[:, 5] + a[:, 6]
+print(f"in-kernel shader clock over the tile: {(tot / a[:, 7]).mean() * 0.1:.2f} GHz (min {(tot / a[:, 7]).min() * 0.1:.2f}, max {(tot / a[:, 7]).max() * 0.1:.2f}); tile wall {a[:, 7].mean() / 100:.1f} us")
 print(f"per tile (wave 0): entry->end of K loop {a[:, 5].mean():9.0f} ticks (loop body {a[:, :4].sum(1).mean():9.0f}), epilogue+store drain {a[:, 6].mean():9.0f} ticks")
