@@ -55,8 +55,9 @@ constexpr int kScaleOne = 0x7F7F7F7F;  // E8M0 127 = 2^0 in every byte
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int BM, int BN, int WM, int WN, int NSTAGE_, int MODE_ = 0, int ABL_ = 0>
+template <int BM, int BN, int WM, int WN, int NSTAGE_, int MODE_ = 0, int ABL_ = 0, int KS_ = 1>
 struct Cfg {
+    static constexpr int KS = KS_;      // K-steps (of 128 bytes) per ring stage: KS = 2 halves the barriers per byte
     static constexpr int ABL = ABL_;    // timing-only ablation bits (diagnostic library only; 0 in the product)
     static constexpr int MODE = MODE_;  // 0 plain ring loop, 1 ping-pong, 2 software-pipelined
     static constexpr bool PINGPONG = MODE_ == 1;
@@ -72,10 +73,12 @@ struct Cfg {
     static constexpr int TN = WN / 16;
     static constexpr int kGroupsA = BM / 8;  // 8-row staging groups
     static constexpr int kGroupsB = BN / 8;
-    static constexpr int kGroups = kGroupsA + kGroupsB;
-    static constexpr int kGroupsPerWave = kGroups / kWaves;
-    static constexpr int kStageBytes = (BM + BN) * BK;
+    static constexpr int kGroups = kGroupsA + kGroupsB;         // per K-step
+    static constexpr int kStepBytes = (BM + BN) * BK;
+    static constexpr int kGroupsPerWave = KS_ * kGroups / kWaves;  // per stage
+    static constexpr int kStageBytes = KS_ * kStepBytes;
     static_assert(kGroups % kWaves == 0, "staging groups must divide evenly over the waves");
+    static_assert(KS_ == 1 || MODE_ == 0, "multi-step stages are implemented for the plain ring loop only");
     static_assert(NSTAGE_ >= 2 && NSTAGE_ <= 6 && (NSTAGE_ - 1) * kGroupsPerWave <= 63, "vmcnt is a 6-bit counter");
     static_assert(NSTAGE_ * kStageBytes <= 160 * 1024, "LDS is 160 KiB per CU");
     static_assert(MODE_ != 1 || kWaves == 8, "the ping-pong schedule pairs waves w and w + 4 on one SIMD");
@@ -173,10 +176,11 @@ template <typename C>
 FP8MI_DEVICE void issue_group(const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, uint8_t *stage,
                               int wave, int j, int k0, int64_t K, bool null)
 {
-    const int gi = wave + j * C::kWaves;
+    const int gs = wave + j * C::kWaves;
+    const int gi = gs % C::kGroups;
     uint32_t vo = pl.voff[j];
     if (null || (int64_t)k0 + pl.kpos[j] >= K) vo = kOOB;
-    lds_void *dst = (lds_void *)(stage + gi * 1024);
+    lds_void *dst = (lds_void *)(stage + gs * 1024);
     if (gi < C::kGroupsA) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, (int)vo, k0, 0, 0);
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, (int)vo, k0, 0, 0);
 }
@@ -187,11 +191,12 @@ FP8MI_DEVICE void issue_stage(const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra,
 {
 #pragma unroll
     for (int j = 0; j < C::kGroupsPerWave; ++j) {
-        const int gi = wave + j * C::kWaves;  // wave-uniform group index
+        const int gs = wave + j * C::kWaves;  // wave-uniform group index inside the stage
+        const int gi = gs % C::kGroups;
         uint32_t vo = pl.voff[j];
         if (TAIL && (int64_t)k0 + pl.kpos[j] >= K) vo = kOOB;  // K tail: only in the peeled last step
-        // the LDS image is consecutive 1-KiB groups (8 rows x 128 B), A's rows first, then B's
-        lds_void *dst = (lds_void *)(stage + gi * 1024);
+        // the LDS image is consecutive 1-KiB groups (8 rows x 128 B), per K-step A's rows first, then B's
+        lds_void *dst = (lds_void *)(stage + gs * 1024);
         if (gi < C::kGroupsA) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, (int)vo, k0, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, (int)vo, k0, 0, 0);
     }
@@ -238,8 +243,8 @@ template <typename C>
 FP8MI_DEVICE void issue_any(const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
                             uint8_t *stage, int wave, int step, int nk, bool ktail, int64_t K)
 {
-    if (ktail && step == nk - 1) issue_stage<C, true>(pl, ra, rb, stage, wave, step * BK, K);
-    else issue_stage<C, false>(pl, ra, rb, stage, wave, step * BK, K);
+    if (ktail && step == nk - 1) issue_stage<C, true>(pl, ra, rb, stage, wave, step * (BK * C::KS), K);
+    else issue_stage<C, false>(pl, ra, rb, stage, wave, step * (BK * C::KS), K);
 }
 
 template <typename C, bool SCRUB>
@@ -253,8 +258,8 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
         for (int tm = 0; tm < C::TM; ++tm) acc[tn][tm] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     const int64_t K = p.K;
-    const int nk = (int)((K + BK - 1) / BK);
-    const bool ktail = (K % BK) != 0;  // then the last step is staged with per-lane K masking
+    const int nk = (int)((K + BK * C::KS - 1) / (BK * C::KS));
+    const bool ktail = (K % (BK * C::KS)) != 0;  // then the last step is staged with per-lane K masking
     if (nk == 0) return;
 
     // The K loop is walked circularly from `rot` (a per-m-tile offset): the tiles
@@ -286,7 +291,9 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
         }
         STAMP(s3);
         if constexpr (C::ABL == 0) {
-            compute_step<C, SCRUB>(smem + slot * C::kStageBytes, wm0, wn0, off1, off2, acc);
+#pragma unroll
+            for (int q = 0; q < C::KS; ++q)
+                compute_step<C, SCRUB>(smem + slot * C::kStageBytes + q * C::kStepBytes, wm0, wn0, off1, off2, acc);
         } else {  // timing-only ablations (diagnostic library): 1 no LDS-DMA, 2 no ds_read, 4 no MFMA
             i32x8 xf_[C::TM], wf_[C::TN];
             if constexpr (!(C::ABL & 2)) load_frags<C, SCRUB>(smem + slot * C::kStageBytes, wm0, wn0, off1, off2, xf_, wf_);
@@ -343,8 +350,8 @@ FP8MI_DEVICE void run_tile_pingpong(const MMParams &p, uint8_t *smem, const Stag
         for (int tm = 0; tm < C::TM; ++tm) acc[tn][tm] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     const int64_t K = p.K;
-    const int nk = (int)((K + BK - 1) / BK);
-    const bool ktail = (K % BK) != 0;
+    const int nk = (int)((K + BK * C::KS - 1) / (BK * C::KS));
+    const bool ktail = (K % (BK * C::KS)) != 0;
     if (nk == 0) return;
     int ks = rot;
     auto next_ks = [&]() { const int r = ks; ks = (ks + 1 == nk) ? 0 : ks + 1; return r; };
@@ -599,8 +606,8 @@ FP8MI_DEVICE void run_tile_swp(const MMParams &p, uint8_t *smem, const StagePlan
 #pragma unroll
         for (int tm = 0; tm < C::TM; ++tm) acc[tn][tm] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const int64_t K = p.K;
-    const int nk = (int)((K + BK - 1) / BK);
-    const bool ktail = (K % BK) != 0;
+    const int nk = (int)((K + BK * C::KS - 1) / (BK * C::KS));
+    const bool ktail = (K % (BK * C::KS)) != 0;
     if (nk == 0) return;
     int ks = rot;
     // prologue: fill the whole ring
@@ -642,7 +649,7 @@ FP8MI_DEVICE void run_tile_interleaved(const MMParams &p, uint8_t *smem, const S
 #pragma unroll
         for (int tm = 0; tm < C::TM; ++tm) acc[tn][tm] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const int64_t K = p.K;
-    const int nk = (int)((K + BK - 1) / BK);
+    const int nk = (int)((K + BK * C::KS - 1) / (BK * C::KS));
     if (nk == 0) return;
     constexpr int G = C::kGroupsPerWave, NM = C::TM * C::TN;
     constexpr int MPG = (NM + G - 1) / G;  // MFMAs per DMA issue
@@ -697,10 +704,10 @@ FP8MI_DEVICE void run_tile_any(const MMParams &p, uint8_t *smem, const StagePlan
     else run_tile<C, SCRUB>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, rot, acc);
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int PP, int ABL>
-__global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL>::kThreads)) void gemm_kernel(MMParams p, int tiles_m, int vec_store)
+template <int BM, int BN, int WM, int WN, int NSTAGE, int PP, int ABL, int KS>
+__global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS>::kThreads)) void gemm_kernel(MMParams p, int tiles_m, int vec_store)
 {
-    using C = Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL>;
+    using C = Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS>;
     __shared__ __attribute__((aligned(16))) uint8_t smem[NSTAGE * C::kStageBytes];
 
     unsigned long long k0_ = 0, k1_ = 0, k2_ = 0; (void)k0_; (void)k1_; (void)k2_;
@@ -732,14 +739,16 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL>::kThreads)) v
     StagePlan<C> pl;
 #pragma unroll
     for (int j = 0; j < C::kGroupsPerWave; ++j) {
-        const int gi = wave + j * C::kWaves;
+        const int gs = wave + j * C::kWaves;         // group index inside the stage
+        const int q = gs / C::kGroups;               // K-step inside the stage
+        const int gi = gs % C::kGroups;              // group inside that K-step
         const bool is_a = gi < C::kGroupsA;
         const int row = (is_a ? gi : gi - C::kGroupsA) * 8 + (lane >> 3);  // row inside the tile
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);                  // source-side swizzle
         const int64_t rows = is_a ? rows_a : rows_b;
         const int64_t ld = is_a ? p.lda : p.ldb;
-        pl.kpos[j] = (uint32_t)(chunk * 16);
-        pl.voff[j] = row < rows ? (uint32_t)(row * ld + chunk * 16) : kOOB;
+        pl.kpos[j] = (uint32_t)(q * BK + chunk * 16);
+        pl.voff[j] = row < rows ? (uint32_t)(row * ld + q * BK + chunk * 16) : kOOB;
     }
 
     // ---- fragment read offsets (lane constant): row r = lane & 15, lane group g = lane >> 4
@@ -748,7 +757,7 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL>::kThreads)) v
     const uint32_t off1 = (uint32_t)(fr * BK + ((fg ^ (fr >> 1)) << 4));
     const uint32_t off2 = (uint32_t)(fr * BK + (((4 + fg) ^ (fr >> 1)) << 4));
 
-    const int nk_all = (int)((p.K + BK - 1) / BK);
+    const int nk_all = (int)((p.K + BK * C::KS - 1) / (BK * C::KS));
     const int rot = (int)(((int64_t)tile_m * nk_all) / tiles_m);  // in [0, nk)
 
     f32x4 acc[C::TN][C::TM];
@@ -794,16 +803,16 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL>::kThreads)) v
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int PP = 0, int ABL = 0>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int PP = 0, int ABL = 0, int KS = 1>
 int launch(const MMParams &p, hipStream_t s)
 {
-    using C = Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL>;
+    using C = Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS>;
     const int64_t tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     if (tm * tn > 0x7FFFFFFF) return FP8MI_E_UNSUPPORTED;
     const int esz = p.out_dtype == FP8MI_F32 ? 4 : 2;
     // 16-byte aligned rows and 4-element groups: enables the vector stores of both epilogues
     const int vec = (((p.ldc * esz) % 16) == 0 && (((uintptr_t)p.C) % 16) == 0) ? 1 : 0;
-    FP8MI_LAUNCH((gemm_kernel<BM, BN, WM, WN, NSTAGE, PP, ABL>), dim3((unsigned)(tm * tn)), dim3(C::kThreads), s, p, (int)tm,
+    FP8MI_LAUNCH((gemm_kernel<BM, BN, WM, WN, NSTAGE, PP, ABL, KS>), dim3((unsigned)(tm * tn)), dim3(C::kThreads), s, p, (int)tm,
                        vec);
     return (int)hipGetLastError();
 }
@@ -861,6 +870,9 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     case 24: return launch<128, 64, 64, 32, 6, 3>(p, s);                       // interleaved, 4 waves
     case 25: return launch<256, 128, 64, 64, 3, 3>(p, s);                      // interleaved
     case 26: return launch<128, 128, 64, 32, 4, 3>(p, s);                      // interleaved, 8 waves
+    case 27: return launch<128, 64, 32, 32, 3, 0, 0, 2>(p, s);                 // 2 K-steps per stage, 3 x 48 KiB
+    case 28: return launch<128, 64, 64, 32, 3, 0, 0, 2>(p, s);                 // same, 4 waves
+    case 29: return launch<128, 128, 64, 32, 2, 0, 0, 2>(p, s);                // 2 x 64 KiB
 #ifdef FP8MI_ABLATE  // diagnostic library only: 10x = 128x64 8-wave, 11x = 256x256; x = ablation bits
     case 101: return launch<128, 64, 32, 32, 6, 0, 1>(p, s);
     case 102: return launch<128, 64, 32, 32, 6, 0, 2>(p, s);
