@@ -18,6 +18,7 @@ Workloads (BASELINE.json configs):
   flux     M=4096, K=3072, N=12288, bf16 out (configs[3]); with --gpus N > 1 the
            N dimension is column-sharded over the ranks and the output is
            all-gathered over RCCL/xGMI ("strong" scaling: fixed total work)
+  skinny   M=4, K=N=4096               (the reference's batch-4 shape, README.md:77; GB/s)
   quantize / dequant   2^30 elements   (configs[4])
 
 Two objects ride on the line: `roofline` for the dominant kernel - algorithmic
@@ -90,13 +91,15 @@ def clean_bytes(shape, dev, gen):
 class Workload:
     """One named workload: buffers + a `launch(i)` closure calling the C ABI."""
 
-    def __init__(self, name, dev, world=1, rank=0, kernel=L.KERNEL_AUTO, nbuf=None):
+    def __init__(self, name, dev, world=1, rank=0, kernel=L.KERNEL_AUTO, nbuf=None, sharded=False):
         self.name, self.dev, self.world, self.rank, self.kernel = name, dev, world, rank, kernel
+        self.sharded = sharded or world > 1
         self.lib = L.load()
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)
         self.collective = None
-        if name in ("gemm", "gemv", "flux"):
-            M, K, N = {"gemm": (512, 4096, 4096), "gemv": (1, 14336, 4096), "flux": (4096, 3072, 12288)}[name]
+        if name in ("gemm", "gemv", "flux", "skinny"):
+            M, K, N = {"gemm": (512, 4096, 4096), "gemv": (1, 14336, 4096), "flux": (4096, 3072, 12288),
+                       "skinny": (4, 4096, 4096)}[name]
             self.M, self.K, self.N_total = M, K, N
             Nl = N // world
             assert N % world == 0
@@ -110,14 +113,16 @@ class Workload:
             self.sb = torch.full((1,), 0.01, dtype=torch.float32, device=dev)
             self.flops = 2.0 * M * Nl * K
             self.bytes = float(M * K + Nl * K + esz * M * Nl)
-            self.unit_flops = name != "gemv"
+            self.unit_flops = name not in ("gemv", "skinny")   # weight-streaming shapes are quoted in GB/s
             self.inner = nbuf * (4 if name == "gemv" else 1)
-            if world > 1:
-                # rank r computes C^T[r] = B_r . A^T (N/w x M, row-major) so that the
-                # all-gather along dim 0 lands the full C^T (N x M) contiguously;
-                # C is its .t() view - no post-gather shuffle.
+            if self.sharded:
+                # the shipped N-column-sharded linear (fp8_sharded_linear.py): transposed blocks,
+                # chunk-cyclic rows, all-gather of chunk j on a side stream under the GEMM of chunk j+1
+                from fp8_sharded_linear import ColumnShardedFP8Linear
+                self.chunks = 4
+                self.linears = [ColumnShardedFP8Linear(B, self.sb, None, N=N, chunks=self.chunks, out_dtype=self.out_dtype)
+                                for B in self.Bs]
                 self.Cs = [torch.empty(Nl, M, dtype=self.out_dtype, device=dev) for _ in range(2)]
-                self.Cfull = [torch.empty(N, M, dtype=self.out_dtype, device=dev) for _ in range(2)]
             else:
                 self.Cs = [torch.empty(M, Nl, dtype=self.out_dtype, device=dev) for _ in range(2)]
             self.code = L.BF16 if name == "flux" else L.F32
@@ -145,7 +150,7 @@ class Workload:
 
     def launch(self, i, stream):
         lib = self.lib
-        if self.name in ("gemm", "gemv", "flux"):
+        if self.name in ("gemm", "gemv", "flux", "skinny"):
             B = self.Bs[i % len(self.Bs)]
             C = self.Cs[i % 2]
             if self.world > 1:  # transposed product: "A" operand = weight shard, "B_nk" operand = activations
@@ -165,17 +170,19 @@ class Workload:
 
     def step(self):
         """One step, eagerly on the current stream (also what gets captured)."""
+        if self.sharded:
+            for i in range(self.inner):
+                self.out = self.linears[i % len(self.linears)](self.A, self.sa)  # (M, N) view of the gathered C^T
+            return
         s = torch.cuda.current_stream(self.dev).cuda_stream
         for i in range(self.inner):
             self.launch(i, s)
-            if self.world > 1:
-                dist.all_gather_into_tensor(self.Cfull[i % 2], self.Cs[i % 2])
 
 
 def time_steps(w, steps, warmup, use_graph, world):
     dev = w.dev
     graph = None
-    if use_graph and world == 1:
+    if use_graph and world == 1 and not w.sharded:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -230,6 +237,9 @@ def roofline_of(w, kd, info, traffic):
         ach = w.bytes / kd["avg_s"] / 1e9
         r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
     r["frac"] = round(r["achieved"] / r["peak"], 4)
+    # informational: what this part sustains in isolation (profiles/r01_peak_probe.txt):
+    # register-only fp8 MFMA loop on weight-like bytes; 4 GiB streaming read
+    r["measured_ceiling"] = 4200.0 if w.unit_flops else 5700.0
     r["traffic"] = traffic
     r["kernel_avg_us"] = round(kd["avg_s"] * 1e6, 3)
     r["kernel_min_us"] = round(kd["min_s"] * 1e6, 3)
@@ -249,7 +259,7 @@ def cpu_baseline(w, budget_s=12.0):
     vp, sz = ctypes.c_void_p, ctypes.c_size_t
     import numpy as np
     rng = np.random.default_rng(1234)
-    if w.name in ("gemm", "gemv", "flux"):
+    if w.name in ("gemm", "gemv", "flux", "skinny"):
         K, N = w.K, min(w.N_total, 4096)
         B = rng.integers(0, 127, size=(N, K), dtype=np.uint8)
         sa = np.array([0.01], np.float32)
@@ -262,12 +272,10 @@ def cpu_baseline(w, budget_s=12.0):
                              sa.ctypes.data_as(vp), sz(rows), sz(N), sz(K), sz(1), sz(1))
             return time.perf_counter() - t0
 
-        probe_rows = 1 if w.M == 1 else 8
-        run(probe_rows)
-        t = run(probe_rows)
-        rows = w.M if w.M == 1 else int(max(probe_rows, min(w.M, probe_rows * budget_s / max(t, 1e-6))))
-        reps = max(1, int(budget_s / max(t * rows / probe_rows, 1e-6))) if w.M == 1 else 1
-        reps = min(reps, 200)
+        rows = w.M if w.M <= 512 else 512   # a 512-row slab of larger problems
+        run(rows)                            # warm-up (page faults, OpenMP pool)
+        t = run(rows)
+        reps = int(min(400, max(1, round(budget_s / max(t, 1e-6)))))
         tt = sum(run(rows) for _ in range(reps))
         if w.unit_flops:
             val, unit = 2.0 * rows * N * K * reps / tt / 1e12, "TFLOP/s"
@@ -306,8 +314,8 @@ def load_traffic(name):
         return None
 
 
-def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info, nbuf=None):
-    w = Workload(name, dev, world, rank, kernel, nbuf)
+def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info, nbuf=None, sharded=False):
+    w = Workload(name, dev, world, rank, kernel, nbuf, sharded)
     dt, graphed = time_steps(w, steps, warmup, True, world)
     launches = steps * w.inner
     if w.unit_flops:
@@ -330,7 +338,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="auto", choices=["auto", "gemm", "gemv", "flux", "quantize", "dequant"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "gemm", "gemv", "flux", "skinny", "quantize", "dequant"])
     ap.add_argument("--kernel", type=int, default=L.KERNEL_AUTO, help="force an FP8MI_KERNEL_* id")
     ap.add_argument("--nbuf", type=int, default=None, help="override the number of rotating weight buffers "
                     "(1 = weights stay cache-resident; for sensitivity experiments only)")
@@ -338,6 +346,8 @@ def main():
                     help="operand byte distribution (see clean_bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="rehearse the multi-GPU code path (sharded linear + RCCL all-gather) with a 1-rank group")
     args = ap.parse_args()
     global DATA_MODE
     DATA_MODE = args.data
@@ -349,8 +359,11 @@ def main():
         raise SystemExit("bench.py needs a HIP device; the product has no CPU path")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    if world > 1:
+    if world > 1 or args.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     if args.gpus != world and rank == 0:
         log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
@@ -359,31 +372,33 @@ def main():
 
     primary = args.workload
     if primary == "auto":
-        primary = "gemm" if world == 1 else "flux"
+        primary = "gemm" if world == 1 and not args.force_sharded else "flux"
     if world > 1 and primary != "flux":
         raise SystemExit("multi-GPU runs shard the FLUX linear (configs[3]); use --workload flux or auto")
 
     res = measure(primary, dev, args.steps, args.warmup, world, rank, args.kernel,
-                  with_cpu=(world == 1 and rank == 0 and not args.no_cpu_baseline), info=info, nbuf=args.nbuf)
+                  with_cpu=(world == 1 and rank == 0 and not args.no_cpu_baseline and not args.force_sharded),
+                  info=info, nbuf=args.nbuf, sharded=args.force_sharded)
     line = {
         "metric": METRIC, "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
         "scaling": "strong" if primary == "flux" else "weak", "vs_baseline": None,
-        "dtype": "fp8_e4m3fn (fp32 accumulate)" if primary in ("gemm", "gemv", "flux") else "u8",
+        "dtype": "fp8_e4m3fn (fp32 accumulate)" if primary in ("gemm", "gemv", "flux", "skinny") else "u8",
         "data": {"gauss": "synthetic (seeded N(0,1) amax-quantised to e4m3fn; weights rotate through > 256 MiB)",
                  "uniform": "synthetic (seeded uniform e4m3 bytes, NaN patterns remapped; weights rotate through > 256 MiB)",
                  "zeros": "synthetic (all-zero bytes; clock upper bound, not a reportable number)"}[args.data],
         "config": dict(res["config"], launches_per_step=res["launches_per_step"], hip_graph=res["hip_graph"],
-                       parallelism=("N-column-sharded x%d + RCCL all-gather" % world) if world > 1 else "single GPU",
+                       parallelism=("N-column-sharded x%d, 4 chunk-cyclic row chunks per rank, RCCL all-gather "
+                                    "pipelined under the GEMM (fp8_sharded_linear.py)" % world) if world > 1 else "single GPU",
                        device=info["name"], arch=info["arch"], compute_units=info["compute_units"]),
         "roofline": res["roofline"],
     }
     if "cpu_baseline" in res:
         line["cpu_baseline"] = res["cpu_baseline"]
 
-    if world == 1 and args.workload == "auto" and not args.no_secondary:
+    if world == 1 and args.workload == "auto" and not args.no_secondary and not args.force_sharded:
         sec = {}
-        for name in ("gemv", "flux", "quantize", "dequant"):
+        for name in ("gemv", "flux", "skinny", "quantize", "dequant"):
             try:
                 r = measure(name, dev, max(3, args.steps // 2), max(1, args.warmup // 2), 1, 0, L.KERNEL_AUTO,
                             with_cpu=(name == "gemv" and not args.no_cpu_baseline), info=info)
@@ -394,7 +409,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

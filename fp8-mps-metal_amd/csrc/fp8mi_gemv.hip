@@ -41,7 +41,7 @@ FP8MI_DEVICE void decode16(const u32x4 &w, f32x2 (&f)[8])
     }
 }
 
-template <int STEPS, int RB>
+template <int STEPS, int RB, bool NT = true>
 __global__ __launch_bounds__(kThreads) void gemv_kernel(MMParams p)
 {
     __shared__ float part[kWaves][RB];
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kThreads) void gemv_kernel(MMParams p)
             const uint8_t *wr = W + (row0 + r) * p.ldb;
 #pragma unroll
             for (int i = 0; i < STEPS; ++i) {
-                if (rv && kv[i]) w[r][i] = __builtin_nontemporal_load((const u32x4 *)(wr + kb[i]));
+                if (rv && kv[i]) w[r][i] = NT ? __builtin_nontemporal_load((const u32x4 *)(wr + kb[i])) : *(const u32x4 *)(wr + kb[i]);
                 else w[r][i] = u32x4{0u, 0u, 0u, 0u};
             }
         }
@@ -156,11 +156,11 @@ __global__ __launch_bounds__(kThreads) void gemv_kernel(MMParams p)
     }
 }
 
-template <int STEPS, int RB>
+template <int STEPS, int RB, bool NT = true>
 int launch(const MMParams &p, hipStream_t s)
 {
     const int64_t grid = (p.N + RB - 1) / RB;
-    FP8MI_LAUNCH((gemv_kernel<STEPS, RB>), dim3((unsigned)grid), dim3(kThreads), s, p);
+    FP8MI_LAUNCH((gemv_kernel<STEPS, RB, NT>), dim3((unsigned)grid), dim3(kThreads), s, p);
     return (int)hipGetLastError();
 }
 

@@ -102,7 +102,8 @@ class ColumnShardedFP8Linear:
         M = x_u8.shape[0]
         dev = x_u8.device
         out_t = torch.empty(self.N, M, dtype=self.out_dtype, device=dev)  # C^T
-        on_gpu = dev.type == "cuda" and self.world > 1
+        grouped = dist.is_initialized()          # a 1-rank group still takes the collective path
+        on_gpu = dev.type == "cuda" and grouped
         if on_gpu and self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=dev)
         handles = []
@@ -114,7 +115,7 @@ class ColumnShardedFP8Linear:
             if self.bias is not None:
                 part.add_(self.bias[lo:hi].to(part.dtype)[:, None])
             block = out_t[j * self.world * self.nc:(j + 1) * self.world * self.nc]
-            if self.world == 1:
+            if not grouped:
                 block.copy_(part)
             elif on_gpu:
                 ev = torch.cuda.Event()

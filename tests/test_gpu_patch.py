@@ -166,3 +166,33 @@ def test_fp8_linear_call_site_flux_shapes(patch, native, cuda, oracle):
     ref = x @ w.t()
     assert y.shape == (M, N) and y.dtype == torch.bfloat16
     assert oracle.rel_rmse(y.float().cpu().numpy(), ref.cpu().numpy()) < 0.06
+
+
+def test_sharded_linear_on_gpu_single_rank_group(native, cuda, oracle):
+    """The N-column-sharded linear through its collective branch (RCCL, side
+    stream, events) with a 1-rank group - all one GPU allows; world 2 runs
+    under gloo in tests/test_sharded_gloo.py."""
+    import torch.distributed as dist
+    from fp8_sharded_linear import ColumnShardedFP8Linear
+    g = torch.Generator().manual_seed(3)
+    M, K, N = 96, 512, 256
+    x = torch.randint(0, 120, (M, K), dtype=torch.uint8, generator=g).to(cuda)
+    W = torch.randint(0, 120, (N, K), dtype=torch.uint8, generator=g).to(cuda)
+    sb = (torch.rand(N, generator=g) * 0.01 + 0.005).to(cuda)
+    bias = torch.randn(N, generator=g).to(cuda)
+    sa = torch.tensor([0.02], device=cuda)
+    exact = oracle.scaled_mm(x.cpu().numpy(), W.cpu().numpy(), [0.02], sb.cpu().numpy(), accumulate="f64") + bias.cpu().numpy()[None, :]
+    bound = oracle.abs_dot_bound(x.cpu().numpy(), W.cpu().numpy(), [0.02], sb.cpu().numpy()) + bias.abs().cpu().numpy()[None, :]
+    lin = ColumnShardedFP8Linear.from_full(W, sb, bias, chunks=4, out_dtype=torch.float32)   # no group: plain copy
+    y0 = lin(x, sa)
+    assert y0.shape == (M, N) and np.all(np.abs(y0.cpu().numpy() - exact) <= 1e-3 * bound)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda)
+    try:
+        lin = ColumnShardedFP8Linear.from_full(W, sb, bias, chunks=4, out_dtype=torch.float32)
+        y1 = lin(x, sa)
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y0)
+    finally:
+        dist.destroy_process_group()
