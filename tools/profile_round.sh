@@ -1,0 +1,39 @@
+#!/bin/bash
+# Round profile on the GPU box: kernel trace of the default bench + HBM traffic counters per workload.
+#   tools/profile_round.sh <tag>        (writes gpurun_out/prof_<tag>/...)
+set -o pipefail
+tag=${1:-rXX}
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$tag; rm -rf $O; mkdir -p $O; cd $R
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python bench.py --steps 10 --warmup 3 > $O/bench_under_rocprof.json 2> $O/kt.err || { echo "kernel-trace run failed"; tail -5 $O/kt.err; exit 1; }
+python tools/summarize_prof.py $O/kt > $O/kernel_trace_summary.txt
+for w in gemm gemv flux skinny quantize dequant; do
+  n=6; [ $w = quantize ] && n=3; [ $w = dequant ] && n=3
+  timeout -k 10 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_$w -o p -- python tools/run_workload.py $w $n > /dev/null 2>&1 || { echo "FETCH pass failed for $w"; exit 1; }
+  timeout -k 10 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_$w -o p -- python tools/run_workload.py $w $n > /dev/null 2>&1 || { echo "WRITE pass failed for $w"; exit 1; }
+done
+python - <<PY
+import csv, glob, json, os, collections
+O = "$O"
+out = {}; lines = []
+for w in ("gemm", "gemv", "flux", "skinny", "quantize", "dequant"):
+    vals = {}
+    for kind in ("fetch", "write"):
+        f = glob.glob(os.path.join(O, f"{kind}_{w}", "**", "*counter_collection.csv"), recursive=True)[0]
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if any(k in r["Kernel_Name"] for k in ("gemm_kernel", "gemv_kernel", "skinny_kernel", "encode_kernel", "dequant_kernel")):
+                agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        k, v = max(agg.items(), key=lambda kv: len(kv[1]))
+        vals[kind] = (sum(v) / len(v), k)
+    fetch_kb, write_kb = vals["fetch"][0], vals["write"][0]
+    # MI355X_MICROARCH.md HBM: on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads -> x2;
+    # WRITE_SIZE is exact for 16-byte-per-lane streaming stores.  Units: KiB.
+    traffic = int((2 * fetch_kb + write_kb) * 1024)
+    out[w] = traffic
+    lines.append(f"{w:9s} FETCH_SIZE {fetch_kb:12.1f} KiB (x2 gfx950 correction)  WRITE_SIZE {write_kb:12.1f} KiB  -> traffic/launch {traffic:14d} B   [{vals['fetch'][1][:70]}]")
+json.dump(out, open(os.path.join(O, "pmc_traffic.json"), "w"), indent=1)
+open(os.path.join(O, "pmc_traffic_summary.txt"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+PY
+cat $O/kernel_trace_summary.txt | head -14
