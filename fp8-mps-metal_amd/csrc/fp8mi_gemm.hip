@@ -30,7 +30,9 @@
 //     s_barrier - a __syncthreads() would drain the DMA queue (vmcnt(0)) and
 //     expose a full memory round trip per K-step (measured on the 2-stage
 //     version of this kernel: 49-66 % of wave time parked in waits,
-//     profiles/r01_v1_*).  One barrier per K-step.
+//     profiles/r01_v1_*).  One barrier per K-step.  (Ping-pong wave groups, an
+//     in-wave software pipeline and interleaved DMA issue were built and
+//     measured too - none beat this loop, see DESIGN.md 5 - and were removed.)
 //   * output orientation: the W fragment is the MFMA "A" operand and the X
 //     fragment the "B" operand, so each lane ends up with 4 CONSECUTIVE n of
 //     one row m in an accumulator register quad -> one 16-byte store.
@@ -59,10 +61,7 @@ template <int BM, int BN, int WM, int WN, int NSTAGE_, int MODE_ = 0, int ABL_ =
 struct Cfg {
     static constexpr int KS = KS_;      // K-steps (of 128 bytes) per ring stage: KS = 2 halves the barriers per byte
     static constexpr int ABL = ABL_;    // timing-only ablation bits (diagnostic library only; 0 in the product)
-    static constexpr int MODE = MODE_;  // 0 plain ring loop, 1 ping-pong, 2 software-pipelined
-    static constexpr bool PINGPONG = MODE_ == 1;
-    static constexpr int TMS = (WM / 16) >= 2 ? 2 : 1;       // X fragments per register window
-    static constexpr int SUBS = (WM / 16) / TMS;             // sub-steps per K-step
+    static constexpr int MODE = MODE_;  // reserved (0 = the ring loop below; other schedules were measured and dropped)
     static constexpr int NSTAGE = NSTAGE_;
     static constexpr int PF = NSTAGE_ - 1;  // K-steps of loads in flight
     static constexpr int kWavesM = BM / WM;
@@ -78,10 +77,9 @@ struct Cfg {
     static constexpr int kGroupsPerWave = KS_ * kGroups / kWaves;  // per stage
     static constexpr int kStageBytes = KS_ * kStepBytes;
     static_assert(kGroups % kWaves == 0, "staging groups must divide evenly over the waves");
-    static_assert(KS_ == 1 || MODE_ == 0, "multi-step stages are implemented for the plain ring loop only");
     static_assert(NSTAGE_ >= 2 && NSTAGE_ <= 6 && (NSTAGE_ - 1) * kGroupsPerWave <= 63, "vmcnt is a 6-bit counter");
     static_assert(NSTAGE_ * kStageBytes <= 160 * 1024, "LDS is 160 KiB per CU");
-    static_assert(MODE_ != 1 || kWaves == 8, "the ping-pong schedule pairs waves w and w + 4 on one SIMD");
+    static_assert(MODE_ == 0, "only the ring loop is built");
 };
 
 // one K-step's fragments: LDS -> registers
@@ -127,33 +125,6 @@ FP8MI_DEVICE void mfma_all(const i32x8 (&xf)[C::TM], const i32x8 (&wf)[C::TN], f
                                                                             kScaleOne, 0, kScaleOne);
 }
 
-// ---- pieces of a K-step for the software-pipelined loop ---------------------
-template <typename C, bool SCRUB, int N>
-FP8MI_DEVICE void read_frags(const uint8_t *rows, uint32_t off1, uint32_t off2, i32x8 (&f)[N])
-{
-#pragma unroll
-    for (int t = 0; t < N; ++t) {
-        i32x4 lo = *(const i32x4 *)(rows + t * 16 * BK + off1);
-        i32x4 hi = *(const i32x4 *)(rows + t * 16 * BK + off2);
-        f[t] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        if (SCRUB) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[t][j] = (int)scrub_nan4((uint32_t)f[t][j]);
-        }
-    }
-}
-
-template <typename C, int TMS>
-FP8MI_DEVICE void mfma_window(const i32x8 (&xw)[TMS], const i32x8 (&wf)[C::TN], f32x4 (&acc)[C::TN][C::TM], int tm0)
-{
-#pragma unroll
-    for (int tn = 0; tn < C::TN; ++tn)
-#pragma unroll
-        for (int i = 0; i < TMS; ++i)
-            acc[tn][tm0 + i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[tn], xw[i], acc[tn][tm0 + i], 0, 0, 0,
-                                                                                kScaleOne, 0, kScaleOne);
-}
-
 template <typename C, bool SCRUB>
 FP8MI_DEVICE void compute_step(const uint8_t *stage, int a_row0, int b_row0, uint32_t off1, uint32_t off2,
                                f32x4 (&acc)[C::TN][C::TM])
@@ -168,22 +139,6 @@ struct StagePlan {
     uint32_t voff[C::kGroupsPerWave];  // per-lane byte offset inside the operand's buffer, or kOOB
     uint32_t kpos[C::kGroupsPerWave];  // chunk*16: position of this lane's 16 bytes inside the K-step
 };
-
-// one staging group (1 KiB for this wave); `null` points every lane outside the
-// buffer: a DMA that only writes zeros - used to keep the issue unconditional
-// (and the per-stage vmcnt bookkeeping uniform) past the last K-step
-template <typename C>
-FP8MI_DEVICE void issue_group(const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, uint8_t *stage,
-                              int wave, int j, int k0, int64_t K, bool null)
-{
-    const int gs = wave + j * C::kWaves;
-    const int gi = gs % C::kGroups;
-    uint32_t vo = pl.voff[j];
-    if (null || (int64_t)k0 + pl.kpos[j] >= K) vo = kOOB;
-    lds_void *dst = (lds_void *)(stage + gs * 1024);
-    if (gi < C::kGroupsA) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, (int)vo, k0, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, (int)vo, k0, 0, 0);
-}
 
 template <typename C, bool TAIL>
 FP8MI_DEVICE void issue_stage(const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
@@ -328,87 +283,6 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
     __builtin_amdgcn_s_barrier();
 }
 
-// Ping-pong K loop (8 waves = two groups of 4; waves w and w + 4 share a SIMD).
-// Group 1 runs half a K-step behind group 0, so in every half-step one group is
-// in its MFMA phase (priority raised: the matrix pipe never idles waiting for
-// issue slots) while the other reads its fragments from LDS and issues the
-// LDS-DMA of a later stage.  Per half-step h (one raw barrier after each):
-//     h = 2t   : g0  issue(t+PF), frags(t) -> regs      g1  issue(t+PF), MFMA(t-1)
-//     h = 2t+1 : g0  MFMA(t), wait stage t+1            g1  frags(t) -> regs, wait stage t+1
-//     h = 2nk  :                                         g1  MFMA(nk-1)
-// Slot of stage t-1 is last read in h = 2t-1 and refilled from h = 2t; stage t+1
-// is complete (every wave's share, then the barrier) before h = 2t+2.  Both
-// groups execute exactly 2 barriers per K-step.
-template <typename C, bool SCRUB>
-FP8MI_DEVICE void run_tile_pingpong(const MMParams &p, uint8_t *smem, const StagePlan<C> &pl,
-                                    __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int wave, int wm0, int wn0,
-                                    uint32_t off1, uint32_t off2, int rot, f32x4 (&acc)[C::TN][C::TM])
-{
-#pragma unroll
-    for (int tn = 0; tn < C::TN; ++tn)
-#pragma unroll
-        for (int tm = 0; tm < C::TM; ++tm) acc[tn][tm] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
-    const int64_t K = p.K;
-    const int nk = (int)((K + BK * C::KS - 1) / (BK * C::KS));
-    const bool ktail = (K % (BK * C::KS)) != 0;
-    if (nk == 0) return;
-    int ks = rot;
-    auto next_ks = [&]() { const int r = ks; ks = (ks + 1 == nk) ? 0 : ks + 1; return r; };
-
-#pragma unroll
-    for (int s = 0; s < C::PF; ++s)
-        if (s < nk) issue_any<C>(pl, ra, rb, smem + s * C::kStageBytes, wave, next_ks(), nk, ktail, K);
-    wait_stage<C>(min(C::PF - 1, nk - 1));  // stage 0
-    __builtin_amdgcn_s_barrier();
-
-    i32x8 xf[C::TM], wf[C::TN];
-    int slot = 0, fill = C::PF % C::NSTAGE;
-    if (wave < C::kWaves / 2) {
-        for (int t = 0; t < nk; ++t) {
-            // ---- h = 2t ----
-            if (t + C::PF < nk) issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, next_ks(), nk, ktail, K);
-            load_frags<C, SCRUB>(smem + slot * C::kStageBytes, wm0, wn0, off1, off2, xf, wf);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            // ---- h = 2t + 1 ----
-            __builtin_amdgcn_s_setprio(1);
-            mfma_all<C>(xf, wf, acc);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < nk) wait_stage<C>(min(C::PF - 1, nk - 2 - t));  // stage t+1
-            __builtin_amdgcn_s_barrier();
-            slot = (slot + 1 == C::NSTAGE) ? 0 : slot + 1;
-            fill = (fill + 1 == C::NSTAGE) ? 0 : fill + 1;
-        }
-    } else {
-        for (int t = 0; t < nk; ++t) {
-            // ---- h = 2t ----
-            if (t + C::PF < nk) issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, next_ks(), nk, ktail, K);
-            if (t > 0) {
-                __builtin_amdgcn_s_setprio(1);
-                mfma_all<C>(xf, wf, acc);
-                __builtin_amdgcn_s_setprio(0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            // ---- h = 2t + 1 ----
-            load_frags<C, SCRUB>(smem + slot * C::kStageBytes, wm0, wn0, off1, off2, xf, wf);
-            if (t + 1 < nk) wait_stage<C>(min(C::PF - 1, nk - 2 - t));  // stage t+1 (also lgkmcnt(0))
-            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            slot = (slot + 1 == C::NSTAGE) ? 0 : slot + 1;
-            fill = (fill + 1 == C::NSTAGE) ? 0 : fill + 1;
-        }
-        // ---- h = 2 nk ----
-        mfma_all<C>(xf, wf, acc);
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // ring reusable (NaN re-run) / everyone done before the epilogue
-}
-
 // Fused epilogue, in the reference's order (fp8_matmul.metal:144-146, then
 // fp8_mps_patch.py:94-104): (acc * sa) * sb, + bias, * scale_result, cast.
 // Lane (fr = lane & 15, fg = lane >> 4) holds, per 16x16 fragment (tn, tm), the
@@ -549,159 +423,12 @@ FP8MI_DEVICE void epilogue_staged(const MMParams &p, const f32x4 (&acc)[C::TN][C
     }
 }
 
-// Software-pipelined K loop.  Inside every wave the LDS reads and the LDS-DMA
-// issue for what comes NEXT run under the MFMAs of what is current:
-//   * the W fragments (TN x 8 VGPRs) are double-buffered across K-steps,
-//   * the X fragments stream through a 2-deep register window of TMS fragments
-//     (a K-step = SUBS sub-steps of TMS x TN MFMAs),
-//   * one barrier per K-step, placed before the LAST sub-step: by then every read
-//     of the current slot has been issued (and is waited for), so the slot is
-//     refilled right there with stage t + NSTAGE, and the first fragments of step
-//     t+1 are fetched under the last sub-step's MFMAs.
-// NSTAGE stages are in flight after the prologue, NSTAGE-1 at every wait.
-template <typename C, bool SCRUB, int PAR>
-FP8MI_DEVICE void swp_step(uint8_t *smem, const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
-                           int wave, int wm0, int wn0, uint32_t off1, uint32_t off2, int t, int nk, bool ktail, int64_t K,
-                           int &slot, int &ks, i32x8 (&wf)[2][C::TN], i32x8 (&xw)[2][C::TMS], f32x4 (&acc)[C::TN][C::TM])
-{
-    constexpr int SUBS = C::SUBS, TMS = C::TMS;
-    const uint8_t *cur = smem + slot * C::kStageBytes;
-    const int nslot = (slot + 1 == C::NSTAGE) ? 0 : slot + 1;
-    const uint8_t *nxt = smem + nslot * C::kStageBytes;
-    const uint8_t *xrows = cur + wm0 * BK;
-#pragma unroll
-    for (int q = 0; q < SUBS; ++q) {
-        constexpr int kDummy = 0; (void)kDummy;
-        const int wq = (q + (SUBS & 1) * PAR) & 1;  // window holding sub-step q's X fragments
-        if (q + 1 < SUBS) {
-            read_frags<C, SCRUB, TMS>(xrows + (q + 1) * TMS * 16 * BK, off1, off2, xw[wq ^ 1]);
-        } else {
-            // every read of `cur` is issued; wait for them and for stage t+1, then refill `cur`
-            if (t + 1 < nk) wait_stage<C>(min(C::NSTAGE - 2, nk - 2 - t));
-            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (t + C::NSTAGE < nk) {
-                issue_any<C>(pl, ra, rb, smem + slot * C::kStageBytes, wave, ks, nk, ktail, K);
-                ks = (ks + 1 == nk) ? 0 : ks + 1;
-            }
-            if (t + 1 < nk) {
-                read_frags<C, SCRUB, TMS>(nxt + wm0 * BK, off1, off2, xw[wq ^ 1]);
-                read_frags<C, SCRUB, C::TN>(nxt + (C::kGroupsA * 8 + wn0) * BK, off1, off2, wf[PAR ^ 1]);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_window<C, TMS>(xw[wq], wf[PAR], acc, q * TMS);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    slot = nslot;
-}
-
-template <typename C, bool SCRUB>
-FP8MI_DEVICE void run_tile_swp(const MMParams &p, uint8_t *smem, const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra,
-                               __amdgpu_buffer_rsrc_t rb, int wave, int wm0, int wn0, uint32_t off1, uint32_t off2,
-                               int rot, f32x4 (&acc)[C::TN][C::TM])
-{
-#pragma unroll
-    for (int tn = 0; tn < C::TN; ++tn)
-#pragma unroll
-        for (int tm = 0; tm < C::TM; ++tm) acc[tn][tm] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    const int64_t K = p.K;
-    const int nk = (int)((K + BK * C::KS - 1) / (BK * C::KS));
-    const bool ktail = (K % (BK * C::KS)) != 0;
-    if (nk == 0) return;
-    int ks = rot;
-    // prologue: fill the whole ring
-#pragma unroll
-    for (int s = 0; s < C::NSTAGE; ++s)
-        if (s < nk) {
-            issue_any<C>(pl, ra, rb, smem + s * C::kStageBytes, wave, ks, nk, ktail, K);
-            ks = (ks + 1 == nk) ? 0 : ks + 1;
-        }
-    wait_stage<C>(min(C::NSTAGE - 1, nk - 1));  // stage 0
-    __builtin_amdgcn_s_barrier();
-    i32x8 wf[2][C::TN], xw[2][C::TMS];
-    read_frags<C, SCRUB, C::TMS>(smem + wm0 * BK, off1, off2, xw[0]);
-    read_frags<C, SCRUB, C::TN>(smem + (C::kGroupsA * 8 + wn0) * BK, off1, off2, wf[0]);
-    int slot = 0;
-    int t = 0;
-    for (; t + 1 < nk; t += 2) {
-        swp_step<C, SCRUB, 0>(smem, pl, ra, rb, wave, wm0, wn0, off1, off2, t, nk, ktail, K, slot, ks, wf, xw, acc);
-        swp_step<C, SCRUB, 1>(smem, pl, ra, rb, wave, wm0, wn0, off1, off2, t + 1, nk, ktail, K, slot, ks, wf, xw, acc);
-    }
-    if (t < nk) swp_step<C, SCRUB, 0>(smem, pl, ra, rb, wave, wm0, wn0, off1, off2, t, nk, ktail, K, slot, ks, wf, xw, acc);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // ring idle: reusable by the NaN re-run / the staged epilogue
-}
-
-// Ring loop with the LDS-DMA issue INTERLEAVED into the MFMA stream: a wave that
-// issues its G loads back to back stalls in the address path (the CU takes ~16
-// cycles per 1-KiB instruction) before its first MFMA; here each group of
-// MFMAs is followed by one DMA issue, so the matrix pipe starts at once and the
-// loads trickle out underneath it.  The issue is unconditional (a null DMA past
-// the last K-step) so that it lives in the MFMAs' basic block.
-template <typename C, bool SCRUB>
-FP8MI_DEVICE void run_tile_interleaved(const MMParams &p, uint8_t *smem, const StagePlan<C> &pl,
-                                       __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int wave, int wm0, int wn0,
-                                       uint32_t off1, uint32_t off2, int rot, f32x4 (&acc)[C::TN][C::TM])
-{
-#pragma unroll
-    for (int tn = 0; tn < C::TN; ++tn)
-#pragma unroll
-        for (int tm = 0; tm < C::TM; ++tm) acc[tn][tm] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    const int64_t K = p.K;
-    const int nk = (int)((K + BK * C::KS - 1) / (BK * C::KS));
-    if (nk == 0) return;
-    constexpr int G = C::kGroupsPerWave, NM = C::TM * C::TN;
-    constexpr int MPG = (NM + G - 1) / G;  // MFMAs per DMA issue
-    int ks = rot;
-    auto next_ks = [&]() { const int r = ks; ks = (ks + 1 == nk) ? 0 : ks + 1; return r; };
-#pragma unroll
-    for (int s = 0; s < C::PF; ++s) {
-        const bool null = s >= nk;
-        const int k0 = (null ? 0 : next_ks()) * BK;
-#pragma unroll
-        for (int j = 0; j < G; ++j) issue_group<C>(pl, ra, rb, smem + s * C::kStageBytes, wave, j, k0, K, null);
-    }
-    int slot = 0, fill = C::PF % C::NSTAGE;
-    for (int t = 0; t < nk; ++t) {
-        wait_loads_and_lds<(C::PF - 1) * G>();  // uniform count: null DMAs keep PF stages issued ahead at all times
-        __builtin_amdgcn_s_barrier();
-        const bool null = t + C::PF >= nk;
-        const int k0 = (null ? 0 : next_ks()) * BK;
-        uint8_t *dst = smem + fill * C::kStageBytes;
-        i32x8 xf[C::TM], wf[C::TN];
-        load_frags<C, SCRUB>(smem + slot * C::kStageBytes, wm0, wn0, off1, off2, xf, wf);
-#pragma unroll
-        for (int i = 0; i < NM; ++i) {
-            const int tn = i / C::TM, tm = i % C::TM;
-            acc[tn][tm] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0, kScaleOne, 0,
-                                                                            kScaleOne);
-            if ((i + 1) % MPG == 0 && (i + 1) / MPG <= G) issue_group<C>(pl, ra, rb, dst, wave, (i + 1) / MPG - 1, k0, K, null);
-        }
-#pragma unroll
-        for (int j = NM / MPG; j < G; ++j) issue_group<C>(pl, ra, rb, dst, wave, j, k0, K, null);
-        // pin the emitted order: MPG MFMAs, then one DMA issue, G times
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-            __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);  // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read (the LDS-DMA)
-        }
-        slot = (slot + 1 == C::NSTAGE) ? 0 : slot + 1;
-        fill = (fill + 1 == C::NSTAGE) ? 0 : fill + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
-
 template <typename C, bool SCRUB>
 FP8MI_DEVICE void run_tile_any(const MMParams &p, uint8_t *smem, const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra,
                                __amdgpu_buffer_rsrc_t rb, int wave, int wm0, int wn0, uint32_t off1, uint32_t off2,
                                int rot, f32x4 (&acc)[C::TN][C::TM])
 {
-    if constexpr (C::MODE == 1) run_tile_pingpong<C, SCRUB>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, rot, acc);
-    else if constexpr (C::MODE == 2) run_tile_swp<C, SCRUB>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, rot, acc);
-    else if constexpr (C::MODE == 3) run_tile_interleaved<C, SCRUB>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, rot, acc);
-    else run_tile<C, SCRUB>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, rot, acc);
+    run_tile<C, SCRUB>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, rot, acc);
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int PP, int ABL, int KS>
@@ -847,32 +574,12 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     switch (variant) {
     case FP8MI_KERNEL_GEMM_128: return launch<128, 128, 64, 32, 2>(p, s);     // 8 waves, 2 x 32 KiB: 2 workgroups / CU
     case FP8MI_KERNEL_GEMM_128x64: return launch<128, 64, 32, 32, 6>(p, s);    // 8 waves, 6 x 24 KiB ring
-    case 2002: return launch<128, 128, 64, 64, 4>(p, s);                       // (4 waves, 4 x 32 KiB ring)
-    case 2005: return launch<128, 64, 64, 32, 6>(p, s);                        // (4 waves, 6 x 24 KiB ring)
     case FP8MI_KERNEL_GEMM_256: return launch<256, 256, 128, 64, 2>(p, s);     // 8 waves, 2 x 64 KiB
-    case 7: return launch<128, 64, 32, 32, 6>(p, s);                           // 8 waves (2 per SIMD)
-    case 8: return launch<128, 128, 64, 32, 4>(p, s);                          // 8 waves
-    case 9: return launch<256, 128, 64, 64, 3>(p, s);                          // 8 waves, 3 x 48 KiB ring
-    case 10: return launch<128, 64, 32, 32, 3>(p, s);                          // 8 waves, 72 KiB: 2 blocks / CU
-    case 11: return launch<128, 128, 64, 32, 2>(p, s);                         // 8 waves, 64 KiB: 2 blocks / CU
-    case 12: return launch<256, 256, 128, 64, 2, 1>(p, s);                  // ping-pong, 2 x 64 KiB
-    case 13: return launch<128, 64, 32, 32, 6, 1>(p, s);                    // ping-pong, 6 x 24 KiB
-    case 14: return launch<128, 128, 64, 32, 4, 1>(p, s);                   // ping-pong, 4 x 32 KiB
-    case 15: return launch<256, 128, 64, 64, 3, 1>(p, s);                   // ping-pong, 3 x 48 KiB
-    case 16: return launch<256, 256, 128, 64, 2, 2>(p, s);                     // software-pipelined
-    case 17: return launch<128, 64, 64, 32, 6, 2>(p, s);                       // swp, 4 waves
-    case 18: return launch<128, 64, 32, 32, 6, 2>(p, s);                       // swp, 8 waves
-    case 19: return launch<128, 128, 64, 64, 4, 2>(p, s);                      // swp, 4 waves
-    case 20: return launch<256, 128, 64, 64, 3, 2>(p, s);                      // swp, 8 waves
-    case 21: return launch<128, 128, 64, 32, 4, 2>(p, s);                      // swp, 8 waves
-    case 22: return launch<256, 256, 128, 64, 2, 3>(p, s);                     // interleaved issue
-    case 23: return launch<128, 64, 32, 32, 6, 3>(p, s);                       // interleaved, 8 waves
-    case 24: return launch<128, 64, 64, 32, 6, 3>(p, s);                       // interleaved, 4 waves
-    case 25: return launch<256, 128, 64, 64, 3, 3>(p, s);                      // interleaved
-    case 26: return launch<128, 128, 64, 32, 4, 3>(p, s);                      // interleaved, 8 waves
-    case 27: return launch<128, 64, 32, 32, 3, 0, 0, 2>(p, s);                 // 2 K-steps per stage, 3 x 48 KiB
-    case 28: return launch<128, 64, 64, 32, 3, 0, 0, 2>(p, s);                 // same, 4 waves
-    case 29: return launch<128, 128, 64, 32, 2, 0, 0, 2>(p, s);                // 2 x 64 KiB
+    // schedule variants kept for A/B timing (same results): tools/bq.sh <workload> <id>
+    case 7: return launch<128, 64, 64, 32, 6>(p, s);                           // 128x64, 4 waves
+    case 8: return launch<128, 128, 64, 64, 4>(p, s);                          // 128x128, 4 waves, 4-stage ring
+    case 9: return launch<256, 128, 64, 64, 3>(p, s);                          // 256x128, 8 waves, 3 x 48 KiB
+    case 10: return launch<128, 64, 32, 32, 3, 0, 0, 2>(p, s);                 // 128x64, two K-steps per stage
 #ifdef FP8MI_ABLATE  // diagnostic library only: 10x = 128x64 8-wave, 11x = 256x256; x = ablation bits
     case 101: return launch<128, 64, 32, 32, 6, 0, 1>(p, s);
     case 102: return launch<128, 64, 32, 32, 6, 0, 2>(p, s);

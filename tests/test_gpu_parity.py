@@ -48,7 +48,7 @@ def clean_bytes(rng, shape):
 
 
 def uses_mfma(kernel, M, K):
-    if kernel in (L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256, L.KERNEL_SKINNY):
+    if kernel in (L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256, L.KERNEL_SKINNY) or kernel >= 7:
         return True
     return kernel == L.KERNEL_AUTO and M > 1 and K % 16 == 0 and K > 0
 
@@ -426,6 +426,51 @@ def test_fused_epilogue(native, cuda, oracle, out_dtype, M):
     exact = oracle.scaled_mm(A, B, [0.01], [0.02], accumulate="f64") + bb.float().numpy()[None, :]
     bound = oracle.abs_dot_bound(A, B, [0.01], [0.02]) + np.abs(bb.float().numpy())[None, :]
     assert np.all(np.abs(got - exact) <= (MFMA_TOL if M > 1 else MM_TOL) * bound + 1e-30)
+
+
+@pytest.mark.parametrize("kernel", [L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256, 7, 8, 9, 10])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_full_tile_staged_epilogue(native, cuda, oracle, kernel, out_dtype):
+    """Interior (full) tiles take the LDS-staged, line-coalesced epilogue: per-row
+    scales, bias and result scale must land on the right rows / columns in every
+    tile variant and output type (ids >= 7 are the schedule variants kept for A/B timing)."""
+    rng = np.random.default_rng(55)
+    M, K, N = 512, 384, 768
+    A = clean_bytes(rng, (M, K))
+    B = clean_bytes(rng, (N, K))
+    sa = rng.uniform(0.005, 0.02, size=M).astype(np.float32)
+    sb = rng.uniform(0.005, 0.02, size=N).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    check_mm(oracle, native, cuda, A, B, sa, sb, kernel=kernel, bias=bias, scale_result=0.25, out_dtype=out_dtype)
+
+
+def test_graph_capture_of_the_c_abi(native, cuda, oracle):
+    """Entry points only enqueue (no sync, no allocation): capturable in a HIP graph."""
+    rng = np.random.default_rng(56)
+    A, B = clean_bytes(rng, (64, 256)), clean_bytes(rng, (128, 256))
+    a, b = dev(A, cuda), dev(B, cuda)
+    s1 = torch.full((1,), 0.5, device=cuda)
+    x = torch.randn(4096, device=cuda)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        native.fp8_scaled_mm(a, b, s1, s1)
+        native.fp8_quantize(x)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        c = native.fp8_scaled_mm(a, b, s1, s1)
+        q, inv = native.fp8_quantize(x)
+        h = native.fp8_dequantize(q, inv)
+    c.zero_(); q.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    exact = oracle.scaled_mm(A, B, [0.5], [0.5], accumulate="f64")
+    assert np.all(np.abs(c.cpu().numpy() - exact) <= MFMA_TOL * oracle.abs_dot_bound(A, B, [0.5], [0.5]))
+    eq, einv = oracle.quantize(x.cpu().numpy())
+    assert np.array_equal(q.cpu().numpy(), eq) and float(inv.cpu()) == float(einv)
+    assert h.shape == x.shape
 
 
 def test_empty_and_degenerate(native, cuda):
