@@ -21,6 +21,11 @@ import ctypes
 import os
 import threading
 
+# torch first: libfp8mi.so links libamdhip64, and PyTorch-ROCm ships its own copy of that
+# runtime.  Whichever is loaded first serves the whole process; loading ours first and
+# torch's afterwards leaves two HIP runtimes in one process ("no ROCm-capable device").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # FP8MI_LIB_PATH lets a diagnostic build (e.g. libfp8mi_stamp.so) stand in; default is the product library
 LIB_PATH = os.environ.get("FP8MI_LIB_PATH") or os.path.join(_HERE, "libfp8mi.so")

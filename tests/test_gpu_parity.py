@@ -393,6 +393,18 @@ def test_generic_kernel_unaligned(native, cuda, oracle):
     assert np.all(np.abs(got - exact) <= MM_TOL * bound + 1e-30)
 
 
+def test_tall_problem_grid_math(native, cuda, oracle):
+    """M beyond 65535 (grid.y/z split of the generic kernel, many m-tiles of the tile kernels)."""
+    rng = np.random.default_rng(12)
+    M = 70003
+    for (K, N) in ((20, 3), (32, 24)):   # K % 16 != 0 -> generic; aligned -> MFMA tiles
+        A = clean_bytes(rng, (M, K))
+        B = clean_bytes(rng, (N, K))
+        got = native.fp8_scaled_mm(dev(A, cuda), dev(B, cuda), torch.ones(1), torch.ones(1)).cpu().numpy()
+        exact = oracle.scaled_mm(A, B, [1.0], [1.0], accumulate="f64")
+        assert np.all(np.abs(got - exact) <= MFMA_TOL * oracle.abs_dot_bound(A, B, [1.0], [1.0]) + 1e-30)
+
+
 def test_padded_row_stride_no_copy(native, cuda, oracle):
     """lda / ldb > K (16-byte aligned): handled by the tuned kernels without a copy."""
     rng = np.random.default_rng(10)
