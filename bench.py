@@ -119,7 +119,7 @@ class Workload:
                 # the shipped N-column-sharded linear (fp8_sharded_linear.py): transposed blocks,
                 # chunk-cyclic rows, all-gather of chunk j on a side stream under the GEMM of chunk j+1
                 from fp8_sharded_linear import ColumnShardedFP8Linear
-                self.chunks = 4
+                self.chunks = 2   # per-call RCCL latency vs overlap: 2 row chunks per rank
                 self.linears = [ColumnShardedFP8Linear(B, self.sb, None, N=N, chunks=self.chunks, out_dtype=self.out_dtype)
                                 for B in self.Bs]
                 self.Cs = [torch.empty(Nl, M, dtype=self.out_dtype, device=dev) for _ in range(2)]
@@ -388,7 +388,7 @@ def main():
                  "uniform": "synthetic (seeded uniform e4m3 bytes, NaN patterns remapped; weights rotate through > 256 MiB)",
                  "zeros": "synthetic (all-zero bytes; clock upper bound, not a reportable number)"}[args.data],
         "config": dict(res["config"], launches_per_step=res["launches_per_step"], hip_graph=res["hip_graph"],
-                       parallelism=("N-column-sharded x%d, 4 chunk-cyclic row chunks per rank, RCCL all-gather "
+                       parallelism=("N-column-sharded x%d, 2 chunk-cyclic row chunks per rank, RCCL all-gather "
                                     "pipelined under the GEMM (fp8_sharded_linear.py)" % world) if world > 1 else "single GPU",
                        device=info["name"], arch=info["arch"], compute_units=info["compute_units"]),
         "roofline": res["roofline"],

@@ -1,0 +1,24 @@
+"""GPU: the C ABI used from a plain C program - no Python, no torch in the
+process - checked against the C oracle (tests/c/abi_roundtrip.c)."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ORACLE, PKG, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c_abi_roundtrip_without_torch(cuda, tmp_path):
+    exe = str(tmp_path / "abi_roundtrip")
+    # plain gcc: the host side needs nothing but the HIP runtime API header and the two libraries
+    cmd = ["gcc", "-O2", "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "tests", "c", "abi_roundtrip.c"),
+           os.path.join(ORACLE, "fp8_oracle.c"), "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+           "-L" + PKG, "-lfp8mi", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+           "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    subprocess.check_call(cmd)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "C ABI round trip: ok" in out.stdout
