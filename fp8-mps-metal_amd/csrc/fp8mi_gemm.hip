@@ -76,7 +76,8 @@ struct Cfg {
     static constexpr int kStepBytes = (BM + BN) * BK;
     static constexpr int kGroupsPerWave = KS_ * kGroups / kWaves;  // per stage
     static constexpr int kStageBytes = KS_ * kStepBytes;
-    static_assert(kGroups % kWaves == 0, "staging groups must divide evenly over the waves");
+    static_assert(kGroupsA % kWaves == 0 && kGroupsB % kWaves == 0 && kWaves % 2 == 0,
+                  "each wave stages whole groups of both operands; the shared swizzle needs an even wave count");
     static_assert(NSTAGE_ >= 2 && NSTAGE_ <= 6 && (NSTAGE_ - 1) * kGroupsPerWave <= 63, "vmcnt is a 6-bit counter");
     static_assert(NSTAGE_ * kStageBytes <= 160 * 1024, "LDS is 160 KiB per CU");
     static_assert(MODE_ == 0, "only the ring loop is built");
@@ -134,25 +135,38 @@ FP8MI_DEVICE void compute_step(const uint8_t *stage, int a_row0, int b_row0, uin
     mfma_all<C>(xf, wf, acc);
 }
 
+// Per-lane staging plan.  A wave stages kGroupsPerWave 1-KiB groups per stage
+// (8 rows x 128 B each).  Its groups of one operand are kWaves * 8 rows apart and
+// - because kWaves is even - share one swizzled chunk, so the whole plan is two
+// base offsets, a row and a K position; rows are only bounds-checked in ragged
+// (edge) tiles.
 template <typename C>
 struct StagePlan {
-    uint32_t voff[C::kGroupsPerWave];  // per-lane byte offset inside the operand's buffer, or kOOB
-    uint32_t kpos[C::kGroupsPerWave];  // chunk*16: position of this lane's 16 bytes inside the K-step
+    uint32_t va0, vb0;  // byte offset of this lane's 16 bytes in the wave's first A / B group
+    uint32_t row0;      // its row there (the same for A and B)
+    uint32_t kpos;      // chunk * 16: position inside the 128-byte K-step
+    uint32_t sa, sb;    // uniform byte stride between the wave's consecutive A / B groups
+    int rows_a, rows_b; // valid rows of this tile
+    bool full;          // interior tile: no row masking
 };
 
 template <typename C, bool TAIL>
 FP8MI_DEVICE void issue_stage(const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
                               uint8_t *stage, int wave, int k0, int64_t K)
 {
+    constexpr int JA = C::kGroupsA / C::kWaves, JB = C::kGroupsB / C::kWaves, JS = JA + JB;
 #pragma unroll
     for (int j = 0; j < C::kGroupsPerWave; ++j) {
-        const int gs = wave + j * C::kWaves;  // wave-uniform group index inside the stage
-        const int gi = gs % C::kGroups;
-        uint32_t vo = pl.voff[j];
-        if (TAIL && (int64_t)k0 + pl.kpos[j] >= K) vo = kOOB;  // K tail: only in the peeled last step
+        const int q = j / JS, jj = j % JS;            // K-step inside the stage, group inside the K-step
+        const bool is_a = jj < JA;
+        const int jo = is_a ? jj : jj - JA;
+        const int gs = q * C::kGroups + (is_a ? 0 : C::kGroupsA) + wave + jo * C::kWaves;  // LDS group slot (wave-uniform)
+        uint32_t vo = (is_a ? pl.va0 + jo * pl.sa : pl.vb0 + jo * pl.sb) + q * BK;
+        if (!pl.full && (int)(pl.row0 + jo * C::kWaves * 8) >= (is_a ? pl.rows_a : pl.rows_b)) vo = kOOB;
+        if (TAIL && (int64_t)k0 + q * BK + pl.kpos >= K) vo = kOOB;  // K tail: only in the peeled last step
         // the LDS image is consecutive 1-KiB groups (8 rows x 128 B), per K-step A's rows first, then B's
         lds_void *dst = (lds_void *)(stage + gs * 1024);
-        if (gi < C::kGroupsA) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, (int)vo, k0, 0, 0);
+        if (is_a) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, (int)vo, k0, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, (int)vo, k0, 0, 0);
     }
 }
@@ -464,18 +478,18 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS>::kThreads
 
     // ---- per-lane staging plan (loop invariant) --------------------------
     StagePlan<C> pl;
-#pragma unroll
-    for (int j = 0; j < C::kGroupsPerWave; ++j) {
-        const int gs = wave + j * C::kWaves;         // group index inside the stage
-        const int q = gs / C::kGroups;               // K-step inside the stage
-        const int gi = gs % C::kGroups;              // group inside that K-step
-        const bool is_a = gi < C::kGroupsA;
-        const int row = (is_a ? gi : gi - C::kGroupsA) * 8 + (lane >> 3);  // row inside the tile
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);                  // source-side swizzle
-        const int64_t rows = is_a ? rows_a : rows_b;
-        const int64_t ld = is_a ? p.lda : p.ldb;
-        pl.kpos[j] = (uint32_t)(q * BK + chunk * 16);
-        pl.voff[j] = row < rows ? (uint32_t)(row * ld + q * BK + chunk * 16) : kOOB;
+    {
+        const int row0 = wave * 8 + (lane >> 3);                           // row of this lane in the wave's first group
+        const int chunk = (lane & 7) ^ (((wave & 1) * 4 + (lane >> 4)) & 7);  // = (lane & 7) ^ ((row >> 1) & 7) for every group
+        pl.row0 = (uint32_t)row0;
+        pl.kpos = (uint32_t)(chunk * 16);
+        pl.va0 = (uint32_t)(row0 * p.lda + chunk * 16);
+        pl.vb0 = (uint32_t)(row0 * p.ldb + chunk * 16);
+        pl.sa = (uint32_t)(C::kWaves * 8 * p.lda);
+        pl.sb = (uint32_t)(C::kWaves * 8 * p.ldb);
+        pl.rows_a = (int)rows_a;
+        pl.rows_b = (int)rows_b;
+        pl.full = rows_a == BM && rows_b == BN;
     }
 
     // ---- fragment read offsets (lane constant): row r = lane & 15, lane group g = lane >> 4
