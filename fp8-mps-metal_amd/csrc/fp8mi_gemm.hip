@@ -578,7 +578,8 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     if (variant == FP8MI_KERNEL_AUTO) {
         // measured on MI355X: 256x256 once it fills ~3/4 of the CUs; otherwise 128x128
         // with 8 waves and a 2-stage ring (two co-resident workgroups per CU hide each other's
-        // prologue / epilogue); below that the 128x64 / 8-wave / 6-stage variant (one tile per CU)
+        // prologue / epilogue); below that 128x64 / 8 waves / 3 stages of two K-steps (one tile per CU;
+        // half as many barriers and waits per byte as one K-step per stage: -8 % in an interleaved A/B)
         const int64_t t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
         const int64_t t128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
         if (t256 >= 192) variant = FP8MI_KERNEL_GEMM_256;
@@ -587,13 +588,13 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     }
     switch (variant) {
     case FP8MI_KERNEL_GEMM_128: return launch<128, 128, 64, 32, 2>(p, s);     // 8 waves, 2 x 32 KiB: 2 workgroups / CU
-    case FP8MI_KERNEL_GEMM_128x64: return launch<128, 64, 32, 32, 6>(p, s);    // 8 waves, 6 x 24 KiB ring
+    case FP8MI_KERNEL_GEMM_128x64: return launch<128, 64, 32, 32, 3, 0, 0, 2>(p, s);  // 8 waves, 3 x 48 KiB ring, 2 K-steps per stage
     case FP8MI_KERNEL_GEMM_256: return launch<256, 256, 128, 64, 2>(p, s);     // 8 waves, 2 x 64 KiB
     // schedule variants kept for A/B timing (same results): tools/bq.sh <workload> <id>
     case 7: return launch<128, 64, 64, 32, 6>(p, s);                           // 128x64, 4 waves
     case 8: return launch<128, 128, 64, 64, 4>(p, s);                          // 128x128, 4 waves, 4-stage ring
     case 9: return launch<256, 128, 64, 64, 3>(p, s);                          // 256x128, 8 waves, 3 x 48 KiB
-    case 10: return launch<128, 64, 32, 32, 3, 0, 0, 2>(p, s);                 // 128x64, two K-steps per stage
+    case 10: return launch<128, 64, 32, 32, 6>(p, s);                          // 128x64, 8 waves, one K-step per stage (6 x 24 KiB)
 #ifdef FP8MI_ABLATE  // diagnostic library only: 10x = 128x64 8-wave, 11x = 256x256; x = ablation bits
     case 101: return launch<128, 64, 32, 32, 6, 0, 1>(p, s);
     case 102: return launch<128, 64, 32, 32, 6, 0, 2>(p, s);
