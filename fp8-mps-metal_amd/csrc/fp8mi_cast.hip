@@ -14,6 +14,9 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kMaxGrid = 2048;
+#ifndef FP8MI_CAST_UNROLL
+#define FP8MI_CAST_UNROLL 4  // 16-byte loads in flight per lane in the vector cast kernels
+#endif
 
 // ---------------------------------------------------------------------------
 // decode: four packed fp8 bytes -> four halves (two packed dwords), exact.
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void dequant_kernel(const uint8_t *__restri
     const int64_t n16 = count >> 4;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     const u32x4 *in4 = (const u32x4 *)in;
-    constexpr int kUn = 4;
+    constexpr int kUn = FP8MI_CAST_UNROLL;
     for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n16; i0 += stride * kUn) {
         u32x4 w[kUn];
 #pragma unroll
@@ -356,7 +359,7 @@ template <int IN, int MODE>
 __global__ __launch_bounds__(kBlock) void encode_kernel(const void *__restrict__ in, uint8_t *__restrict__ out,
                                                          const float *__restrict__ prescale, int64_t count)
 {
-    constexpr int kPer = InVec<IN>::kPer, kUn = 4;
+    constexpr int kPer = InVec<IN>::kPer, kUn = FP8MI_CAST_UNROLL;
     const bool has_ps = prescale != nullptr;
     const float ps = has_ps ? prescale[0] : 1.0f;
     const int64_t nv = count / kPer;
