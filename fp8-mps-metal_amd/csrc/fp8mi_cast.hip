@@ -355,13 +355,26 @@ struct InVec<FP8MI_BF16> {
 // the input (one contiguous KiB per load instruction) = kPer elements, and
 // stores their kPer bytes at kPer * l (256 / 512 contiguous bytes per store
 // instruction); 4 pieces per lane are in flight.
-template <int IN, int MODE>
+// scale = 448 / amax evaluated in double, as the reference's Python float arithmetic
+// (fp8_mps_native.py:174-176); amax == 0 -> 1
+FP8MI_DEVICE float scale_from_amax(float amax) { return amax > 0.0f ? (float)(448.0 / (double)amax) : 1.0f; }
+
+// FROM_AMAX: `prescale` points at {amax, inv_scale}: every thread derives the scale from
+// amax (read-only here), thread 0 of workgroup 0 publishes float(1 / scale) in slot 1
+// (fp8_mps_native.py:189) - the amax-scaled quantiser without a separate scale kernel.
+template <int IN, int MODE, bool FROM_AMAX = false>
 __global__ __launch_bounds__(kBlock) void encode_kernel(const void *__restrict__ in, uint8_t *__restrict__ out,
                                                          const float *__restrict__ prescale, int64_t count)
 {
     constexpr int kPer = InVec<IN>::kPer, kUn = FP8MI_CAST_UNROLL;
     const bool has_ps = prescale != nullptr;
-    const float ps = has_ps ? prescale[0] : 1.0f;
+    float ps = has_ps ? prescale[0] : 1.0f;
+    if (FROM_AMAX) {
+        const float amax = ps;
+        ps = scale_from_amax(amax);
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            ((float *)prescale)[1] = amax > 0.0f ? (float)(1.0 / (448.0 / (double)amax)) : 1.0f;
+    }
     const int64_t nv = count / kPer;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < nv; i0 += stride * kUn) {
@@ -398,12 +411,18 @@ __global__ __launch_bounds__(kBlock) void encode_kernel(const void *__restrict__
     }
 }
 
-template <int IN, int MODE>
+template <int IN, int MODE, bool FROM_AMAX = false>
 __global__ __launch_bounds__(kBlock) void encode_scalar_kernel(const void *__restrict__ in, uint8_t *__restrict__ out,
                                                                 const float *__restrict__ prescale, int64_t count)
 {
     const bool has_ps = prescale != nullptr;
-    const float ps = has_ps ? prescale[0] : 1.0f;
+    float ps = has_ps ? prescale[0] : 1.0f;
+    if (FROM_AMAX) {
+        const float amax = ps;
+        ps = scale_from_amax(amax);
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            ((float *)prescale)[1] = amax > 0.0f ? (float)(1.0 / (448.0 / (double)amax)) : 1.0f;
+    }
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) {
         float v = InVec<IN>::load1(in, i);
@@ -443,16 +462,6 @@ __global__ __launch_bounds__(kBlock) void amax_kernel(const void *__restrict__ i
     }
 }
 
-// scales[0] = 448/amax (double division, as the reference's Python float
-// arithmetic, fp8_mps_native.py:174-176), scales[1] = float(1/scale) (:189).
-__global__ void quant_scale_kernel(float *scales /* in: [0] = amax */)
-{
-    double amax = (double)scales[0];
-    double scale = amax > 0.0 ? 448.0 / amax : 1.0;
-    scales[0] = (float)scale;
-    scales[1] = (float)(1.0 / scale);
-}
-
 int grid_for(int64_t work_items)
 {
     int64_t g = (work_items + kBlock - 1) / kBlock;
@@ -486,18 +495,18 @@ int fp8mi_launch_dequant(const uint8_t *in, void *out, const float *scale, int64
     return (int)hipGetLastError();
 }
 
-template <int IN>
+template <int IN, bool FROM_AMAX = false>
 static int launch_encode_in(const void *in, uint8_t *out, const float *prescale, int64_t count, int mode,
                             hipStream_t s)
 {
     const bool vec = aligned16(in) && aligned16(out);
     const int grid = grid_for(vec ? (count >> 4) : count);  // >= 4 vectors per lane per pass
     if (mode == FP8MI_ENC_REFERENCE) {
-        if (vec) FP8MI_LAUNCH((encode_kernel<IN, FP8MI_ENC_REFERENCE>), dim3(grid), dim3(kBlock), s, in, out, prescale, count);
-        else FP8MI_LAUNCH((encode_scalar_kernel<IN, FP8MI_ENC_REFERENCE>), dim3(grid), dim3(kBlock), s, in, out, prescale, count);
+        if (vec) FP8MI_LAUNCH((encode_kernel<IN, FP8MI_ENC_REFERENCE, FROM_AMAX>), dim3(grid), dim3(kBlock), s, in, out, prescale, count);
+        else FP8MI_LAUNCH((encode_scalar_kernel<IN, FP8MI_ENC_REFERENCE, FROM_AMAX>), dim3(grid), dim3(kBlock), s, in, out, prescale, count);
     } else {
-        if (vec) FP8MI_LAUNCH((encode_kernel<IN, FP8MI_ENC_RNE>), dim3(grid), dim3(kBlock), s, in, out, prescale, count);
-        else FP8MI_LAUNCH((encode_scalar_kernel<IN, FP8MI_ENC_RNE>), dim3(grid), dim3(kBlock), s, in, out, prescale, count);
+        if (vec) FP8MI_LAUNCH((encode_kernel<IN, FP8MI_ENC_RNE, FROM_AMAX>), dim3(grid), dim3(kBlock), s, in, out, prescale, count);
+        else FP8MI_LAUNCH((encode_scalar_kernel<IN, FP8MI_ENC_RNE, FROM_AMAX>), dim3(grid), dim3(kBlock), s, in, out, prescale, count);
     }
     return (int)hipGetLastError();
 }
@@ -528,10 +537,12 @@ int fp8mi_launch_amax(const void *in, int in_dtype, float *out, int64_t count, h
 int fp8mi_launch_quantize(const void *in, int in_dtype, uint8_t *out, float *scales, int64_t count, int mode,
                           hipStream_t s)
 {
+    // scales[0] <- amax (atomicMax over the input), then one encode launch that derives
+    // scale = 448 / amax per thread and publishes scales[1] = 1 / scale
     int rc = fp8mi_launch_amax(in, in_dtype, scales, count, s);
     if (rc) return rc;
-    FP8MI_LAUNCH(quant_scale_kernel, dim3(1), dim3(1), s, scales);
-    rc = (int)hipGetLastError();
-    if (rc) return rc;
-    return fp8mi_launch_encode(in, in_dtype, out, scales, count, mode, s);
+    // (count == 0 still launches one workgroup: it publishes inv_scale = 1 and touches no data)
+    if (in_dtype == FP8MI_F32) return launch_encode_in<FP8MI_F32, true>(in, out, scales, count, mode, s);
+    if (in_dtype == FP8MI_F16) return launch_encode_in<FP8MI_F16, true>(in, out, scales, count, mode, s);
+    return launch_encode_in<FP8MI_BF16, true>(in, out, scales, count, mode, s);
 }

@@ -144,9 +144,9 @@ int fp8mi_encode(const void *in, int in_dtype, uint8_t *out, const float *presca
 int fp8mi_amax(const void *in, int in_dtype, float *out, int64_t count, void *stream);
 
 /*
- * Amax-scaled quantisation, entirely on the device (no host sync):
+ * Amax-scaled quantisation, entirely on the device (no host sync, two kernels):
  *   amax = max|in|; scale = amax > 0 ? 448/amax : 1   (evaluated in double)
- *   out[i] = enc(float32(in[i]) * float32(scale));  scales[0] = scale,
+ *   out[i] = enc(float32(in[i]) * float32(scale));  scales[0] = amax,
  *   scales[1] = float32(1/scale)  (the inverse scale _scaled_mm consumes)
  * Replaces: fp8_quantize (fp8_mps_native.py:158-190; fp8_bridge.cpp:312-356).
  * `scales` is float[2] device memory owned by the caller.

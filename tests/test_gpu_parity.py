@@ -210,6 +210,8 @@ def test_amax_and_quantize(native, cuda, oracle):
     assert np.array_equal(q.cpu().numpy(), eq) and float(inv.cpu()) == float(einv)
     q0, inv0 = native.fp8_quantize(torch.zeros(33, device=cuda))
     assert float(inv0.cpu()) == 1.0 and not q0.any()
+    qe, inve = native.fp8_quantize(torch.empty(0, device=cuda))
+    assert qe.numel() == 0 and float(inve.cpu()) == 1.0
     x = torch.tensor([0.0, 1.0, -1.0, 0.5, -0.5, 100.0, -100.0, 448.0], device=cuda)
     q, inv = native.fp8_quantize(x)
     back = native.fp8_dequantize(q, inv).float()
