@@ -163,7 +163,7 @@ int fp8mi_scaled_mm_ex(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     case FP8MI_KERNEL_GEMM_128:
     case FP8MI_KERNEL_GEMM_128x64:
     case FP8MI_KERNEL_GEMM_256:
-    case 7: case 8: case 9: case 10:  // schedule variants for A/B timing
+    case 7: case 8: case 9: case 10: case 11: case 12: case 13:  // schedule variants for A/B timing
         if (!fp8mi_gemm_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "MFMA gemm kernel needs K %% 16 == 0 and 16-byte aligned rows");
         return hip_result(fp8mi_launch_gemm(p, kernel, s), "gemm");
     case FP8MI_KERNEL_GENERIC:

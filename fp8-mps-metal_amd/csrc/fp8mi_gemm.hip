@@ -57,11 +57,11 @@ constexpr int kScaleOne = 0x7F7F7F7F;  // E8M0 127 = 2^0 in every byte
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int BM, int BN, int WM, int WN, int NSTAGE_, int MODE_ = 0, int ABL_ = 0, int KS_ = 1>
+template <int BM, int BN, int WM, int WN, int NSTAGE_, int MODE_ = 0, int ABL_ = 0, int KS_ = 1, int LD_ = 0>
 struct Cfg {
     static constexpr int KS = KS_;      // K-steps (of 128 bytes) per ring stage: KS = 2 halves the barriers per byte
     static constexpr int ABL = ABL_;    // timing-only ablation bits (diagnostic library only; 0 in the product)
-    static constexpr int MODE = MODE_;  // reserved (0 = the ring loop below; other schedules were measured and dropped, DESIGN.md 5)
+    static constexpr int MODE = MODE_;  // reserved (0 = the ring loop below; other schedules were measured and dropped, DESIGN.md 6)
     static constexpr int NSTAGE = NSTAGE_;
     static constexpr int PF = NSTAGE_ - 1;  // K-steps of loads in flight
     static constexpr int kWavesM = BM / WM;
@@ -74,10 +74,16 @@ struct Cfg {
     static constexpr int kGroupsB = BN / 8;
     static constexpr int kGroups = kGroupsA + kGroupsB;         // per K-step
     static constexpr int kStepBytes = (BM + BN) * BK;
-    static constexpr int kGroupsPerWave = KS_ * kGroups / kWaves;  // per stage
+    // Waves that issue the LDS-DMA (0 = all).  Every 1-KiB DMA instruction takes ~16 cycles in the CU's
+    // one address path and blocks its wave until accepted; with all waves loading, both waves of a SIMD
+    // sit in that queue at the head of each K-step and the matrix pipe idles (measured with in-kernel
+    // stamps).  With kLoaders = kWaves / 2 only waves 0..kLoaders-1 (one per SIMD) load, and their SIMD
+    // partners start the step's fragment reads and MFMAs at once.
+    static constexpr int kLoaders = LD_ == 0 ? kWaves : LD_;
+    static constexpr int kGroupsPerWave = KS_ * kGroups / kLoaders;  // per stage, per loading wave
     static constexpr int kStageBytes = KS_ * kStepBytes;
-    static_assert(kGroupsA % kWaves == 0 && kGroupsB % kWaves == 0 && kWaves % 2 == 0,
-                  "each wave stages whole groups of both operands; the shared swizzle needs an even wave count");
+    static_assert(kGroupsA % kLoaders == 0 && kGroupsB % kLoaders == 0 && kLoaders % 2 == 0 && kLoaders <= kWaves,
+                  "each loading wave stages whole groups of both operands; the shared swizzle needs an even count");
     static_assert(NSTAGE_ >= 2 && NSTAGE_ <= 6 && (NSTAGE_ - 1) * kGroupsPerWave <= 63, "vmcnt is a 6-bit counter");
     static_assert(NSTAGE_ * kStageBytes <= 160 * 1024, "LDS is 160 KiB per CU");
     static_assert(MODE_ == 0, "only the ring loop is built");
@@ -154,15 +160,16 @@ template <typename C, bool TAIL>
 FP8MI_DEVICE void issue_stage(const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
                               uint8_t *stage, int wave, int k0, int64_t K)
 {
-    constexpr int JA = C::kGroupsA / C::kWaves, JB = C::kGroupsB / C::kWaves, JS = JA + JB;
+    constexpr int JA = C::kGroupsA / C::kLoaders, JB = C::kGroupsB / C::kLoaders, JS = JA + JB;
+    if (C::kLoaders < C::kWaves && wave >= C::kLoaders) return;  // wave-uniform: this wave does not load
 #pragma unroll
     for (int j = 0; j < C::kGroupsPerWave; ++j) {
         const int q = j / JS, jj = j % JS;            // K-step inside the stage, group inside the K-step
         const bool is_a = jj < JA;
         const int jo = is_a ? jj : jj - JA;
-        const int gs = q * C::kGroups + (is_a ? 0 : C::kGroupsA) + wave + jo * C::kWaves;  // LDS group slot (wave-uniform)
+        const int gs = q * C::kGroups + (is_a ? 0 : C::kGroupsA) + wave + jo * C::kLoaders;  // LDS group slot (wave-uniform)
         uint32_t vo = (is_a ? pl.va0 + jo * pl.sa : pl.vb0 + jo * pl.sb) + q * BK;
-        if (!pl.full && (int)(pl.row0 + jo * C::kWaves * 8) >= (is_a ? pl.rows_a : pl.rows_b)) vo = kOOB;
+        if (!pl.full && (int)(pl.row0 + jo * C::kLoaders * 8) >= (is_a ? pl.rows_a : pl.rows_b)) vo = kOOB;
         if (TAIL && (int64_t)k0 + q * BK + pl.kpos >= K) vo = kOOB;  // K tail: only in the peeled last step
         // the LDS image is consecutive 1-KiB groups (8 rows x 128 B), per K-step A's rows first, then B's
         lds_void *dst = (lds_void *)(stage + gs * 1024);
@@ -445,10 +452,10 @@ FP8MI_DEVICE void run_tile_any(const MMParams &p, uint8_t *smem, const StagePlan
     run_tile<C, SCRUB>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, rot, acc);
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int PP, int ABL, int KS>
-__global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS>::kThreads)) void gemm_kernel(MMParams p, int tiles_m, int vec_store)
+template <int BM, int BN, int WM, int WN, int NSTAGE, int PP, int ABL, int KS, int LD>
+__global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThreads)) void gemm_kernel(MMParams p, int tiles_m, int vec_store)
 {
-    using C = Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS>;
+    using C = Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>;
     __shared__ __attribute__((aligned(16))) uint8_t smem[NSTAGE * C::kStageBytes];
 
     unsigned long long k0_ = 0, k1_ = 0, k2_ = 0; (void)k0_; (void)k1_; (void)k2_;
@@ -485,8 +492,8 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS>::kThreads
         pl.kpos = (uint32_t)(chunk * 16);
         pl.va0 = (uint32_t)(row0 * p.lda + chunk * 16);
         pl.vb0 = (uint32_t)(row0 * p.ldb + chunk * 16);
-        pl.sa = (uint32_t)(C::kWaves * 8 * p.lda);
-        pl.sb = (uint32_t)(C::kWaves * 8 * p.ldb);
+        pl.sa = (uint32_t)(C::kLoaders * 8 * p.lda);
+        pl.sb = (uint32_t)(C::kLoaders * 8 * p.ldb);
         pl.rows_a = (int)rows_a;
         pl.rows_b = (int)rows_b;
         pl.full = rows_a == BM && rows_b == BN;
@@ -544,16 +551,16 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS>::kThreads
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int PP = 0, int ABL = 0, int KS = 1>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int PP = 0, int ABL = 0, int KS = 1, int LD = 0>
 int launch(const MMParams &p, hipStream_t s)
 {
-    using C = Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS>;
+    using C = Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>;
     const int64_t tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     if (tm * tn > 0x7FFFFFFF) return FP8MI_E_UNSUPPORTED;
     const int esz = p.out_dtype == FP8MI_F32 ? 4 : 2;
     // 16-byte aligned rows and 4-element groups: enables the vector stores of both epilogues
     const int vec = (((p.ldc * esz) % 16) == 0 && (((uintptr_t)p.C) % 16) == 0) ? 1 : 0;
-    FP8MI_LAUNCH((gemm_kernel<BM, BN, WM, WN, NSTAGE, PP, ABL, KS>), dim3((unsigned)(tm * tn)), dim3(C::kThreads), s, p, (int)tm,
+    FP8MI_LAUNCH((gemm_kernel<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>), dim3((unsigned)(tm * tn)), dim3(C::kThreads), s, p, (int)tm,
                        vec);
     return (int)hipGetLastError();
 }
@@ -587,14 +594,17 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
         else variant = FP8MI_KERNEL_GEMM_128x64;
     }
     switch (variant) {
-    case FP8MI_KERNEL_GEMM_128: return launch<128, 128, 64, 32, 2>(p, s);     // 8 waves, 2 x 32 KiB: 2 workgroups / CU
-    case FP8MI_KERNEL_GEMM_128x64: return launch<128, 64, 32, 32, 3, 0, 0, 2>(p, s);  // 8 waves, 3 x 48 KiB ring, 2 K-steps per stage
-    case FP8MI_KERNEL_GEMM_256: return launch<256, 256, 128, 64, 2>(p, s);     // 8 waves, 2 x 64 KiB
+    case FP8MI_KERNEL_GEMM_128: return launch<128, 128, 64, 32, 2, 0, 0, 1, 4>(p, s);  // 8 waves (0-3 load), 2 x 32 KiB: 2 workgroups / CU
+    case FP8MI_KERNEL_GEMM_128x64: return launch<128, 64, 32, 32, 3, 0, 0, 2, 4>(p, s);  // 8 waves (0-3 load), 3 x 48 KiB ring, 2 K-steps per stage
+    case FP8MI_KERNEL_GEMM_256: return launch<256, 256, 128, 64, 2, 0, 0, 1, 4>(p, s);  // 8 waves (0-3 load), 2 x 64 KiB
     // schedule variants kept for A/B timing (same results): tools/bq.sh <workload> <id>
     case 7: return launch<128, 64, 64, 32, 6>(p, s);                           // 128x64, 4 waves
     case 8: return launch<128, 128, 64, 64, 4>(p, s);                          // 128x128, 4 waves, 4-stage ring
-    case 9: return launch<256, 128, 64, 64, 3>(p, s);                          // 256x128, 8 waves, 3 x 48 KiB
+    case 9: return launch<256, 128, 64, 64, 3, 0, 0, 1, 4>(p, s);              // 256x128, 8 waves (0-3 load), 3 x 48 KiB
     case 10: return launch<128, 64, 32, 32, 6>(p, s);                          // 128x64, 8 waves, one K-step per stage (6 x 24 KiB)
+    case 11: return launch<256, 256, 128, 64, 2>(p, s);                        // 256x256, all 8 waves load
+    case 12: return launch<128, 64, 32, 32, 3, 0, 0, 2>(p, s);                 // 128x64 KS=2, all 8 waves load
+    case 13: return launch<128, 128, 64, 32, 2>(p, s);                         // 128x128, all 8 waves load
 #ifdef FP8MI_ABLATE  // diagnostic library only: 10x = 128x64 8-wave, 11x = 256x256; x = ablation bits
     case 101: return launch<128, 64, 32, 32, 6, 0, 1>(p, s);
     case 102: return launch<128, 64, 32, 32, 6, 0, 2>(p, s);
