@@ -84,18 +84,19 @@ struct Cfg {
     static constexpr int kStageBytes = KS_ * kStepBytes;
     static_assert(kGroupsA % kLoaders == 0 && kGroupsB % kLoaders == 0 && kLoaders % 2 == 0 && kLoaders <= kWaves,
                   "each loading wave stages whole groups of both operands; the shared swizzle needs an even count");
+    static constexpr int kRingBytes = NSTAGE_ * kStageBytes;
     static_assert(NSTAGE_ >= 2 && NSTAGE_ <= 6 && (NSTAGE_ - 1) * kGroupsPerWave <= 63, "vmcnt is a 6-bit counter");
-    static_assert(NSTAGE_ * kStageBytes <= 160 * 1024, "LDS is 160 KiB per CU");
+    static_assert(kRingBytes <= 160 * 1024, "LDS is 160 KiB per CU");
     static_assert(MODE_ == 0, "only the ring loop is built");
 };
 
 // one K-step's fragments: LDS -> registers
 template <typename C, bool SCRUB>
-FP8MI_DEVICE void load_frags(const uint8_t *stage, int a_row0 /* m */, int b_row0 /* n */, uint32_t off1, uint32_t off2,
-                             i32x8 (&xf)[C::TM], i32x8 (&wf)[C::TN])
+FP8MI_DEVICE void load_frags(const uint8_t *a_rows, const uint8_t *b_rows, int a_row0 /* m */, int b_row0 /* n */,
+                             uint32_t off1, uint32_t off2, i32x8 (&xf)[C::TM], i32x8 (&wf)[C::TN])
 {
-    const uint8_t *sa = stage + a_row0 * BK;                       // X rows (m) first ...
-    const uint8_t *sB = stage + (C::kGroupsA * 8 + b_row0) * BK;   // ... then W rows (n)
+    const uint8_t *sa = a_rows + a_row0 * BK;   // X rows (m)
+    const uint8_t *sB = b_rows + b_row0 * BK;   // W rows (n)
 #pragma unroll
     for (int t = 0; t < C::TM; ++t) {
         i32x4 lo = *(const i32x4 *)(sa + t * 16 * BK + off1);
@@ -137,7 +138,7 @@ FP8MI_DEVICE void compute_step(const uint8_t *stage, int a_row0, int b_row0, uin
                                f32x4 (&acc)[C::TN][C::TM])
 {
     i32x8 xf[C::TM], wf[C::TN];
-    load_frags<C, SCRUB>(stage, a_row0, b_row0, off1, off2, xf, wf);
+    load_frags<C, SCRUB>(stage, stage + C::kGroupsA * 1024, a_row0, b_row0, off1, off2, xf, wf);  // per K-step: A's rows, then B's
     mfma_all<C>(xf, wf, acc);
 }
 
@@ -189,7 +190,7 @@ FP8MI_DEVICE void issue_stage(const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra,
         __builtin_amdgcn_sched_barrier(0);                                         \
         var = t_;                                                                  \
     } while (0)
-__device__ unsigned long long g_stamp[256 * 8];
+__device__ unsigned long long g_stamp[256 * 32];  // per block: [wave 0 | wave kWaves/2] x 8 sums, then their 5 absolute stamps of step 5
 #else
 #define STAMP(var) do { } while (0)
 #endif
@@ -272,7 +273,7 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
                 compute_step<C, SCRUB>(smem + slot * C::kStageBytes + q * C::kStepBytes, wm0, wn0, off1, off2, acc);
         } else {  // timing-only ablations (diagnostic library): 1 no LDS-DMA, 2 no ds_read, 4 no MFMA
             i32x8 xf_[C::TM], wf_[C::TN];
-            if constexpr (!(C::ABL & 2)) load_frags<C, SCRUB>(smem + slot * C::kStageBytes, wm0, wn0, off1, off2, xf_, wf_);
+            if constexpr (!(C::ABL & 2)) load_frags<C, SCRUB>(smem + slot * C::kStageBytes, smem + slot * C::kStageBytes + C::kGroupsA * 1024, wm0, wn0, off1, off2, xf_, wf_);
             else {
 #pragma unroll
                 for (int i = 0; i < C::TM; ++i) xf_[i] = i32x8{t, t, t, t, t, t, t, t};
@@ -289,14 +290,19 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
         }
         STAMP(s4);
         c_wait += s1 - s0; c_bar += s2 - s1; c_issue += s3 - s2; c_comp += s4 - s3;
+#ifdef FP8MI_STAMP
+        if (t == 5 && (threadIdx.x & 63) == 0 && blockIdx.x < 256 && (wave == 0 || wave == C::kWaves / 2)) {
+            unsigned long long *o = g_stamp + blockIdx.x * 32 + 16 + (wave ? 5 : 0);
+            o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = s4;
+        }
+#endif
         slot = (slot + 1 == C::NSTAGE) ? 0 : slot + 1;
         fill = (fill + 1 == C::NSTAGE) ? 0 : fill + 1;
     }
 #ifdef FP8MI_STAMP
-    if (threadIdx.x == 0 && blockIdx.x < 256) {
-        g_stamp[blockIdx.x * 8 + 0] = c_wait; g_stamp[blockIdx.x * 8 + 1] = c_bar;
-        g_stamp[blockIdx.x * 8 + 2] = c_issue; g_stamp[blockIdx.x * 8 + 3] = c_comp;
-        g_stamp[blockIdx.x * 8 + 4] = nk;
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && (wave == 0 || wave == C::kWaves / 2)) {
+        unsigned long long *o = g_stamp + blockIdx.x * 32 + (wave ? 8 : 0);
+        o[0] = c_wait; o[1] = c_bar; o[2] = c_issue; o[3] = c_comp; o[4] = nk;
     }
 #endif
     // all loads were waited for in the last iteration (newer_stages == 0); make the ring reusable
@@ -390,7 +396,7 @@ FP8MI_DEVICE void epilogue_staged(const MMParams &p, const f32x4 (&acc)[C::TN][C
     constexpr int kCPR = kRowBytes / 16;         // 16-byte chunks per row
     constexpr int kRPI = 64 / kCPR;              // rows written per store instruction
     constexpr int kNI = 16 / kRPI;               // store instructions per 16-row fragment
-    static_assert(C::kWaves * 16 * kStride <= C::NSTAGE * C::kStageBytes, "staging fits in the ring");
+    static_assert(C::kWaves * 16 * kStride <= C::kRingBytes, "staging fits in the ring");
     uint8_t *buf = smem + wave * (16 * kStride);
     const int fr = lane & 15, fg = lane >> 4;
 
@@ -456,7 +462,7 @@ template <int BM, int BN, int WM, int WN, int NSTAGE, int PP, int ABL, int KS, i
 __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThreads)) void gemm_kernel(MMParams p, int tiles_m, int vec_store)
 {
     using C = Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>;
-    __shared__ __attribute__((aligned(16))) uint8_t smem[NSTAGE * C::kStageBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t smem[C::kRingBytes];
 
     unsigned long long k0_ = 0, k1_ = 0, k2_ = 0; (void)k0_; (void)k1_; (void)k2_;
     STAMP(k0_);
@@ -544,9 +550,9 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(k2_);
     if (threadIdx.x == 0 && blockIdx.x < 256) {
-        g_stamp[blockIdx.x * 8 + 5] = k1_ - k0_;   // entry .. end of K loop (incl. NaN check)
-        g_stamp[blockIdx.x * 8 + 6] = k2_ - k1_;   // epilogue incl. store drain
-        g_stamp[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime() - r0_;  // 100 MHz ticks over the whole tile
+        g_stamp[blockIdx.x * 32 + 5] = k1_ - k0_;   // entry .. end of K loop (incl. NaN check)
+        g_stamp[blockIdx.x * 32 + 6] = k2_ - k1_;   // epilogue incl. store drain
+        g_stamp[blockIdx.x * 32 + 7] = __builtin_amdgcn_s_memrealtime() - r0_;  // 100 MHz ticks over the whole tile
     }
 #endif
 }

@@ -13,16 +13,23 @@ s = torch.cuda.current_stream(dev).cuda_stream
 for i in range(4): w.launch(i, s)
 torch.cuda.synchronize()
 lib = L.load()
-buf = (ctypes.c_ulonglong * (256 * 8))()
+buf = (ctypes.c_ulonglong * (256 * 32))()
 lib.fp8mi_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
-assert lib.fp8mi_debug_read_stamps(buf, 256 * 8) == 0
+assert lib.fp8mi_debug_read_stamps(buf, 256 * 32) == 0
 import numpy as np
-a = np.array(list(buf), dtype=np.float64).reshape(256, 8)
+full = np.array(list(buf), dtype=np.float64).reshape(256, 32)
+a = full[:, :8]
 nk = a[:, 4].max()
-print(f"{name} kernel {kernel}: nk={int(nk)}; mean cycles per K-step over 256 blocks (wave 0):")
-for i, n in enumerate(("wait(vmcnt)", "barrier", "issue loads", "ds_read+MFMA")):
-    print(f"  {n:14s} {a[:, i].mean() / nk:8.1f}   (min {a[:, i].min() / nk:7.1f}, max {a[:, i].max() / nk:7.1f})")
-print(f"  total          {a[:, :4].sum(1).mean() / nk:8.1f}")
+for wname, b in (("wave 0 (loads)", full[:, 0:8]), ("wave kWaves/2", full[:, 8:16])):
+    print(f"{name} kernel {kernel}: nk={int(nk)}; mean ticks per K-step over 256 blocks, {wname}:")
+    for i, n in enumerate(("wait(vmcnt)", "barrier", "issue loads", "ds_read+MFMA")):
+        print(f"  {n:14s} {b[:, i].mean() / nk:8.1f}   (min {b[:, i].min() / nk:7.1f}, max {b[:, i].max() / nk:7.1f})")
+    print(f"  total          {b[:, :4].sum(1).mean() / nk:8.1f}")
+t0 = full[:, 16:17]
+w0, w4 = full[:, 16:21] - t0, full[:, 21:26] - t0
+print("step 5, ticks relative to wave 0's loop top (mean over blocks):  top  waited  barrier-passed  issued  MFMAs-done")
+print("  wave 0       ", " ".join(f"{x:8.0f}" for x in w0.mean(0)))
+print("  wave kWaves/2", " ".join(f"{x:8.0f}" for x in w4.mean(0)))
 tot = a[:, 5] + a[:, 6]
 print(f"in-kernel shader clock over the tile: {(tot / a[:, 7]).mean() * 0.1:.2f} GHz (min {(tot / a[:, 7]).min() * 0.1:.2f}, max {(tot / a[:, 7]).max() * 0.1:.2f}); tile wall {a[:, 7].mean() / 100:.1f} us")
 print(f"per tile (wave 0): entry->end of K loop {a[:, 5].mean():9.0f} ticks (loop body {a[:, :4].sum(1).mean():9.0f}), epilogue+store drain {a[:, 6].mean():9.0f} ticks")
