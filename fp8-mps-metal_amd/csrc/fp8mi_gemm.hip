@@ -445,7 +445,9 @@ FP8MI_DEVICE void epilogue_staged(const MMParams &p, const f32x4 (&acc)[C::TN][C
         for (int i = 0; i < kNI; ++i) {
             const int r = i * kRPI + rrow;
             u32x4 q = *(const u32x4 *)(buf + r * kStride + rchunk * 16);
-            *(u32x4 *)(grow + (int64_t)r * p.ldc * kEsz + rchunk * 16) = q;
+            // streaming store: C is written once and not re-read by this kernel, so it should not displace the
+            // A / B panels in L2 (measured: C3 -3 %, 128x128 shard -5 %, FLUX -1 %)
+            __builtin_nontemporal_store(q, (u32x4 *)(grow + (int64_t)r * p.ldc * kEsz + rchunk * 16));
         }
     }
 }
