@@ -313,9 +313,12 @@ def test_gemv_shapes(native, cuda, oracle, M, K, N):
 
 @pytest.mark.parametrize("kernel", [L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256])
 @pytest.mark.parametrize("M,K,N", [(1, 128, 1), (5, 16, 3), (128, 128, 128), (130, 272, 70), (300, 1040, 200),
-                                   (256, 512, 256), (257, 384, 513), (64, 4096, 96)])
+                                   (256, 512, 256), (257, 384, 513), (64, 4096, 96),
+                                   (1300, 144, 900), (700, 32, 1100)])
 def test_gemm_tile_kernels_ragged(native, cuda, oracle, kernel, M, K, N):
-    """MFMA tile kernels on full and ragged tiles, K tails (K % 128 != 0) included."""
+    """MFMA tile kernels on full and ragged tiles, K tails (K % 128 != 0) included; the last two shapes
+    give m-tile counts that are not multiples of the tile map's group of 4 and grids that are not
+    multiples of the 8 XCDs (every output element checked, so a tile mapped twice or never shows)."""
     rng = np.random.default_rng(M * 7 + K * 3 + N)
     A = clean_bytes(rng, (M, K))
     B = clean_bytes(rng, (N, K))
