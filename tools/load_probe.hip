@@ -10,7 +10,9 @@
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int MODE, int R>  // 0: buffer_load ... lds, 1: global_load_dwordx4 -> VGPR (+xor sink), 2: VGPR + ds_write_b128
+// PAT (MODE 0 only): 0 = 1 KiB contiguous per instruction; 1 = 8 rows x 128 B, rows 4 KiB apart (the GEMM's staging
+// shape); 2 = the same with the GEMM's XOR swizzle of the 16-byte chunks inside each line; 3 = 4 rows x 256 B
+template <int MODE, int R, int PAT = 0>  // 0: buffer_load ... lds, 1: global_load_dwordx4 -> VGPR (+xor sink), 2: VGPR + ds_write_b128
 __global__ __launch_bounds__(1024) void k(const uint8_t *src, uint32_t *sink, unsigned long long *cyc, int rounds, int span)
 {
     __shared__ __attribute__((aligned(16))) uint8_t smem[64 * 1024];
@@ -26,6 +28,13 @@ __global__ __launch_bounds__(1024) void k(const uint8_t *src, uint32_t *sink, un
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 uint32_t o = (off + j * 1024u * nw + lane * 16u) % (uint32_t)span;
+                if (PAT == 1 || PAT == 2) {
+                    const uint32_t row = lane >> 3, ch = (lane & 7) ^ (PAT == 2 ? ((wave & 1) * 4 + (lane >> 4)) & 7 : 0);
+                    o = ((off / 1024u + j * nw) % 32u * 128u + ((off / 32768u) % 8u) * 32768u * 8u + row * 4096u + ch * 16u) % (uint32_t)span;
+                } else if (PAT == 3) {
+                    const uint32_t row = lane >> 4, ch = lane & 15;
+                    o = ((off / 1024u + j * nw) % 16u * 256u + ((off / 16384u) % 16u) * 16384u * 8u + row * 4096u + ch * 16u) % (uint32_t)span;
+                }
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(smem + ((wave * R + j) % 64) * 1024), 16, (int)o, 0, 0, 0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -50,14 +59,14 @@ __global__ __launch_bounds__(1024) void k(const uint8_t *src, uint32_t *sink, un
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
-template <int MODE, int R>
+template <int MODE, int R, int PAT = 0>
 void run(const char *name, int waves, const uint8_t *src, uint32_t *sink, unsigned long long *cyc, int span)
 {
     const int rounds = 200;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<MODE, R>), 256, waves * 64, 0, 0, src, sink, cyc, 20, span);
+    hipLaunchKernelGGL((k<MODE, R, PAT>), 256, waves * 64, 0, 0, src, sink, cyc, 20, span);
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<MODE, R>), 256, waves * 64, 0, 0, src, sink, cyc, rounds, span);
+    hipLaunchKernelGGL((k<MODE, R, PAT>), 256, waves * 64, 0, 0, src, sink, cyc, rounds, span);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> h(256);
@@ -83,6 +92,12 @@ int main()
         run<0, 16>("LDS-DMA (buffer_load lds)", w, src, sink, cyc, span);
         run<1, 16>("global_load_dwordx4->VGPR", w, src, sink, cyc, span);
         run<2, 16>("VGPR + ds_write_b128", w, src, sink, cyc, span);
+    }
+    for (int w : {4, 8}) {
+        run<0, 16, 0>("DMA 1 KiB contiguous", w, src, sink, cyc, span);
+        run<0, 16, 1>("DMA 8 rows x 128 B", w, src, sink, cyc, span);
+        run<0, 16, 2>("DMA 8 rows x 128 B swizzled", w, src, sink, cyc, span);
+        run<0, 16, 3>("DMA 4 rows x 256 B", w, src, sink, cyc, span);
     }
     return 0;
 }

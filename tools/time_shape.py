@@ -10,19 +10,21 @@ reps = int(sys.argv[6]) if len(sys.argv) > 6 else 40
 nan_mode = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 dev = torch.device("cuda:0"); lib = L.load()
 g = torch.Generator(device=dev).manual_seed(1)
-A = torch.randint(0, 120, (M, K), dtype=torch.uint8, device=dev, generator=g)
-nb = max(2, (320 << 20) // max(N * K, 1)); nb = min(nb, 24)
-Bs = [torch.randint(0, 120, (N, K), dtype=torch.uint8, device=dev, generator=g) for _ in range(nb)]
+PAD = int(os.environ.get("PAD", "0"))  # extra bytes per row (row stride K + PAD): power-of-two strides vs cache sets / channels
+LD = K + PAD
+A = torch.randint(0, 120, (M, LD), dtype=torch.uint8, device=dev, generator=g)
+nb = max(2, (320 << 20) // max(N * LD, 1)); nb = min(nb, 24)
+Bs = [torch.randint(0, 120, (N, LD), dtype=torch.uint8, device=dev, generator=g) for _ in range(nb)]
 C = torch.empty(M, N, dtype=torch.float32 if out == "f32" else torch.bfloat16, device=dev)
 s1 = torch.full((1,), 0.01, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 def run(i):
     L.check(lib.fp8mi_scaled_mm_ex(A.data_ptr(), Bs[i % nb].data_ptr(), C.data_ptr(), s1.data_ptr(), s1.data_ptr(), None, None,
-                                   M, N, K, K, K, N, 0, 0, 0 if out == "f32" else 2, 0, nan_mode, kid, st), "mm")
+                                   M, N, K, LD, LD, N, 0, 0, 0 if out == "f32" else 2, 0, nan_mode, kid, st), "mm")
 for i in range(5): run(i)
 torch.cuda.synchronize()
 with L.kernel_timer(reps) as kt:
     for i in range(reps): run(i)
 torch.cuda.synchronize()
 ms = sorted(kt.ms)
-print(f"M={M} K={K} N={N} kernel={kid} out={out} nan_mode={nan_mode}: avg {sum(ms)/len(ms)*1e3:.2f} us  min {ms[0]*1e3:.2f}  ({2.0*M*N*K/(sum(ms)/len(ms)*1e-3)/1e12:.1f} TFLOP/s)")
+print(f"M={M} K={K} N={N} pad={PAD} kernel={kid} out={out} nan_mode={nan_mode}: avg {sum(ms)/len(ms)*1e3:.2f} us  min {ms[0]*1e3:.2f}  ({2.0*M*N*K/(sum(ms)/len(ms)*1e-3)/1e12:.1f} TFLOP/s)")
