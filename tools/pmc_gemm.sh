@@ -1,5 +1,6 @@
 #!/bin/bash
-# Counter study of one GEMM workload on the GPU box (separate --pmc passes, nothing but counters in each run).
+# SQ-block counter study of one GEMM workload (the TA/TCP/TCC counter sets abort rocprofv3 7.2 on gfx950; each pass
+# takes ~1.5 min because the workload builds > 256 MiB of rotating weights) on the GPU box (separate --pmc passes, nothing but counters in each run).
 #   tools/pmc_gemm.sh <gemm|flux> <tag> [kernel_id]     -> gpurun_out/pmc_<tag>/summary.txt
 set -o pipefail
 w=${1:-gemm}; tag=${2:-x}; kid=${3:-0}
@@ -9,10 +10,6 @@ passes=(
  "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD"
  "SQ_INSTS_VALU_MFMA_MOPS_F8 SQ_INSTS_VALU_MFMA_MOPS_F6F4 SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES"
  "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL"
- "TA_TA_BUSY_sum TA_BUSY_avr TA_BUFFER_TOTAL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_BUFFER_READ_LDS_WAVEFRONTS_sum TA_BUFFER_COALESCED_READ_CYCLES_sum"
- "TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_GATE_EN1_sum"
- "TD_TD_BUSY_sum TD_TC_STALL_sum TD_SPI_STALL_sum TD_LOAD_WAVEFRONT_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCP_LATENCY_sum TCP_TOTAL_READ_sum GRBM_GUI_ACTIVE"
- "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCC_TAG_STALL_sum TCC_BUSY_avr TCC_EA0_RD_UNCACHED_32B_sum TCC_READ_sum"
 )
 i=0
 for p in "${passes[@]}"; do
