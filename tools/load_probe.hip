@@ -30,7 +30,8 @@ __global__ __launch_bounds__(1024) void k(const uint8_t *src, uint32_t *sink, un
                 uint32_t o = (off + j * 1024u * nw + lane * 16u) % (uint32_t)span;
                 if (PAT == 1 || PAT == 2) {
                     const uint32_t row = lane >> 3, ch = (lane & 7) ^ (PAT == 2 ? ((wave & 1) * 4 + (lane >> 4)) & 7 : 0);
-                    o = ((off / 1024u + j * nw) % 32u * 128u + ((off / 32768u) % 8u) * 32768u * 8u + row * 4096u + ch * 16u) % (uint32_t)span;
+                    const uint32_t q = (uint32_t)(r * R + j) * nw + wave;  // the workgroup walks 8-row x 4-KiB blocks
+                    o = (blockIdx.x * (1u << 20) + (q / 32u) * 32768u + row * 4096u + (q % 32u) * 128u + ch * 16u) % (uint32_t)span;
                 } else if (PAT == 3) {
                     const uint32_t row = lane >> 4, ch = lane & 15;
                     o = ((off / 1024u + j * nw) % 16u * 256u + ((off / 16384u) % 16u) * 16384u * 8u + row * 4096u + ch * 16u) % (uint32_t)span;
@@ -60,25 +61,25 @@ __global__ __launch_bounds__(1024) void k(const uint8_t *src, uint32_t *sink, un
 }
 
 template <int MODE, int R, int PAT = 0>
-void run(const char *name, int waves, const uint8_t *src, uint32_t *sink, unsigned long long *cyc, int span)
+void run(const char *name, int waves, const uint8_t *src, uint32_t *sink, unsigned long long *cyc, int span, int grid = 256)
 {
     const int rounds = 200;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<MODE, R, PAT>), 256, waves * 64, 0, 0, src, sink, cyc, 20, span);
+    hipLaunchKernelGGL((k<MODE, R, PAT>), grid, waves * 64, 0, 0, src, sink, cyc, PAT ? rounds : 20, span);  // warm-up (same footprint for the row patterns)
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<MODE, R, PAT>), 256, waves * 64, 0, 0, src, sink, cyc, rounds, span);
+    hipLaunchKernelGGL((k<MODE, R, PAT>), grid, waves * 64, 0, 0, src, sink, cyc, rounds, span);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    std::vector<unsigned long long> h(256);
-    hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost);
-    double avg = 0; for (auto c : h) avg += c; avg /= 256;
+    std::vector<unsigned long long> h(grid);
+    hipMemcpy(h.data(), cyc, grid * 8, hipMemcpyDeviceToHost);
+    double avg = 0; for (auto c : h) avg += c; avg /= grid;
     double instr_per_wave = (double)rounds * R;
     double bytes_cu = instr_per_wave * waves * 1024.0;
     printf("%-26s waves/CU %2d  R %2d: %7.1f cyc per wave-instr, %6.1f GB/s per CU (%5.2f TB/s chip), kernel %.1f us\n", name, waves, R,
-           avg / instr_per_wave, bytes_cu / (ms * 1e-3) / 1e9, bytes_cu * 256 / (ms * 1e-3) / 1e12, ms * 1e3);
+           avg / instr_per_wave, bytes_cu / (ms * 1e-3) / 1e9, bytes_cu * grid / (ms * 1e-3) / 1e12, ms * 1e3);
 }
 
-int main()
+int main(int argc, char **)
 {
     const int span = 2 << 20;  // 2 MiB: L2-resident per XCD
     uint8_t *src; uint32_t *sink; unsigned long long *cyc;
@@ -98,6 +99,17 @@ int main()
         run<0, 16, 1>("DMA 8 rows x 128 B", w, src, sink, cyc, span);
         run<0, 16, 2>("DMA 8 rows x 128 B swizzled", w, src, sink, cyc, span);
         run<0, 16, 3>("DMA 4 rows x 256 B", w, src, sink, cyc, span);
+    }
+    // how much of the per-CU rate is bytes-in-flight / latency: the same stream from L2 (2 MiB), from the Infinity
+    // Cache (96 MiB span, warmed by the first launch) and with 64 instead of 256 CUs active
+    if (argc > 1) {
+        uint8_t *big; hipMalloc(&big, (size_t)1 << 30);
+        hipMemset(big, 1, (size_t)1 << 30);
+        for (int sp : {2 << 20, 16 << 20, 96 << 20, 1 << 30})
+            for (int grid : {64, 256}) {
+                printf("span %4d MiB grid %3d: ", sp >> 20, grid);
+                run<0, 16, 2>("DMA 8x128 swz", 8, big, sink, cyc, sp, grid);
+            }
     }
     return 0;
 }
