@@ -120,10 +120,26 @@ int fp8mi_device_info(int device, fp8mi_device_info_t *out)
     return 0;
 }
 
+int64_t fp8mi_scaled_mm_workspace_bytes(void)
+{
+    // the library only splits on its own when tiles * slices <= 256 workgroups of a 128x64 (or 64x128) tile:
+    // 256 x 32 KiB of fp32 partials + the counters; twice that leaves room for forced splits
+    return (int64_t)FP8MI_WS_COUNTER_BYTES + 2 * 256 * (int64_t)(128 * 64 * 4);
+}
+
 int fp8mi_scaled_mm_ex(const uint8_t *A, const uint8_t *B_nk, void *C, const float *scale_a, const float *scale_b,
                        const void *bias, const float *scale_result, int64_t M, int64_t N, int64_t K, int64_t lda,
                        int64_t ldb, int64_t ldc, int scale_a_mode, int scale_b_mode, int out_dtype, int bias_dtype,
                        int nan_mode, int kernel, void *stream)
+{
+    return fp8mi_scaled_mm_ws(A, B_nk, C, scale_a, scale_b, bias, scale_result, M, N, K, lda, ldb, ldc, scale_a_mode,
+                              scale_b_mode, out_dtype, bias_dtype, nan_mode, kernel, 1, nullptr, 0, stream);
+}
+
+int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const float *scale_a, const float *scale_b,
+                       const void *bias, const float *scale_result, int64_t M, int64_t N, int64_t K, int64_t lda,
+                       int64_t ldb, int64_t ldc, int scale_a_mode, int scale_b_mode, int out_dtype, int bias_dtype,
+                       int nan_mode, int kernel, int split_k, void *workspace, int64_t workspace_bytes, void *stream)
 {
     if (M < 0 || N < 0 || K < 0) return fail(FP8MI_E_SHAPE, "fp8mi_scaled_mm: negative dimension (M=%lld N=%lld K=%lld)",
                                               (long long)M, (long long)N, (long long)K);
@@ -146,12 +162,26 @@ int fp8mi_scaled_mm_ex(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     p.out_dtype = out_dtype; p.bias_dtype = bias_dtype;
     p.nan_zero = nan_mode == FP8MI_NAN_ZERO;
     p.debug = 0;
+    if (split_k < 0) return fail(FP8MI_E_ENUM, "fp8mi_scaled_mm_ws: split_k must be >= 0");
+    if (workspace && ((((uintptr_t)workspace) & 15u) != 0 || workspace_bytes < FP8MI_WS_COUNTER_BYTES)) {
+        workspace = nullptr;  // unusable: behave as if none was given
+    }
+    p.split = workspace ? split_k : 1;
+    p.ws = (uint8_t *)workspace;
+    p.ws_bytes = workspace ? workspace_bytes : 0;
     hipStream_t s = (hipStream_t)stream;
 
     switch (kernel) {
     case FP8MI_KERNEL_AUTO:
         if (fp8mi_gemv_supported(p)) return hip_result(fp8mi_launch_gemv(p, s), "gemv");
-        if (p.M >= 2 && p.M <= 32 && fp8mi_skinny_supported(p)) return hip_result(fp8mi_launch_skinny(p, s), "skinny");
+        if (p.M >= 2 && p.M <= 32 && fp8mi_skinny_supported(p)) {
+            // measured (tools/time_shape.py): the weight-streaming skinny kernel wins up to M = 4 and on small
+            // weight matrices (K = N = 4096: 9-10 vs 12-13 us); from M = 8 on large ones the split-K tile kernel
+            // does (M = 32, K = 14336, N = 4096: 19 vs 30 us) - it needs the workspace
+            const bool big = (double)p.N * (double)p.K >= 32.0 * 1048576.0;
+            if (!(p.ws && p.split != 1 && p.M >= 8 && big && fp8mi_gemm_supported(p)))
+                return hip_result(fp8mi_launch_skinny(p, s), "skinny");
+        }
         if (K > 0 && fp8mi_gemm_supported(p)) return hip_result(fp8mi_launch_gemm(p, FP8MI_KERNEL_AUTO, s), "gemm");
         return hip_result(fp8mi_launch_generic(p, s), "generic");
     case FP8MI_KERNEL_GEMV:
@@ -163,6 +193,7 @@ int fp8mi_scaled_mm_ex(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     case FP8MI_KERNEL_GEMM_128:
     case FP8MI_KERNEL_GEMM_128x64:
     case FP8MI_KERNEL_GEMM_256:
+    case FP8MI_KERNEL_GEMM_64x128:
     case 7: case 8: case 9: case 10: case 11: case 12: case 13:  // schedule variants for A/B timing
         if (!fp8mi_gemm_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "MFMA gemm kernel needs K %% 16 == 0 and 16-byte aligned rows");
         return hip_result(fp8mi_launch_gemm(p, kernel, s), "gemm");

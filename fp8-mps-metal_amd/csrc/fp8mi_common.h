@@ -35,7 +35,12 @@ struct MMParams {
     int out_dtype, bias_dtype;
     int nan_zero;          // 1: NaN bytes decode to 0 (reference), 0: propagate
     int debug;             // diagnostic builds only (FP8MI_STAMP): ablation bits, else 0
+    int split;             // GEMM tile kernels: number of K ranges per tile (1 = no split-K)
+    uint8_t *ws;           // split-K workspace (tile counters, then fp32 partial tiles) or nullptr
+    int64_t ws_bytes;
 };
+
+constexpr int kWsCounterBytes = 4096;  // 1024 tile counters, zero between launches
 
 // SWAR scrub: zero every byte of w whose low 7 bits are all ones (the two
 // e4m3fn NaN patterns 0x7F / 0xFF), i.e. the reference's decode rule

@@ -54,6 +54,7 @@ namespace {
 constexpr int BK = 128;  // bytes (= k elements) per K-step
 constexpr uint32_t kOOB = 0x80000000u;
 constexpr int kScaleOne = 0x7F7F7F7F;  // E8M0 127 = 2^0 in every byte
+static_assert(kWsCounterBytes == FP8MI_WS_COUNTER_BYTES, "include/fp8mi.h and the kernels agree on the counter block");
 
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -227,16 +228,17 @@ FP8MI_DEVICE void issue_any(const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra, _
 template <typename C, bool SCRUB>
 FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra,
                            __amdgpu_buffer_rsrc_t rb, int wave, int wm0, int wn0, uint32_t off1, uint32_t off2,
-                           int rot, f32x4 (&acc)[C::TN][C::TM])
+                           int ks0, int nk, int rot, f32x4 (&acc)[C::TN][C::TM])
 {
+    // ks0, nk: this workgroup's range of ring stages (all of K, or one split-K slice); rot in [0, nk)
 #pragma unroll
     for (int tn = 0; tn < C::TN; ++tn)
 #pragma unroll
         for (int tm = 0; tm < C::TM; ++tm) acc[tn][tm] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     const int64_t K = p.K;
-    const int nk = (int)((K + BK * C::KS - 1) / (BK * C::KS));
-    const bool ktail = (K % (BK * C::KS)) != 0;  // then the last step is staged with per-lane K masking
+    const int nk_all = (int)((K + BK * C::KS - 1) / (BK * C::KS));
+    const bool ktail = (K % (BK * C::KS)) != 0;  // then the tile's last stage is staged with per-lane K masking
     if (nk == 0) return;
 
     // The K loop is walked circularly from `rot` (a per-m-tile offset): the tiles
@@ -244,13 +246,13 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
     // started at k = 0 each of them would wait out HBM latency on the same lines;
     // staggered, each one fetches a different K range from HBM and finds the
     // rest already in the XCD's L2.  (Only the summation order changes.)
-    int ks = rot;  // K-step the next issue loads
-    auto next_ks = [&]() { const int r = ks; ks = (ks + 1 == nk) ? 0 : ks + 1; return r; };
+    int ks = rot;  // stage (relative to ks0) the next issue loads
+    auto next_ks = [&]() { const int r = ks; ks = (ks + 1 == nk) ? 0 : ks + 1; return ks0 + r; };
 
     // prologue: PF stages in flight (stage s -> ring slot s)
 #pragma unroll
     for (int s = 0; s < C::PF; ++s)
-        if (s < nk) issue_any<C>(pl, ra, rb, smem + s * C::kStageBytes, wave, next_ks(), nk, ktail, K);
+        if (s < nk) issue_any<C>(pl, ra, rb, smem + s * C::kStageBytes, wave, next_ks(), nk_all, ktail, K);
 
     int slot = 0;             // ring slot of step t
     int fill = C::PF % C::NSTAGE;  // ring slot the next issue goes to (= slot of step t-1)
@@ -264,7 +266,7 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
         __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave is done reading slot of step t-1
         STAMP(s2);
         if (!(C::ABL & 1)) {
-            if (t + C::PF < nk) issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, next_ks(), nk, ktail, K);
+            if (t + C::PF < nk) issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, next_ks(), nk_all, ktail, K);
         }
         STAMP(s3);
         if constexpr (C::ABL == 0) {
@@ -455,9 +457,9 @@ FP8MI_DEVICE void epilogue_staged(const MMParams &p, const f32x4 (&acc)[C::TN][C
 template <typename C, bool SCRUB>
 FP8MI_DEVICE void run_tile_any(const MMParams &p, uint8_t *smem, const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra,
                                __amdgpu_buffer_rsrc_t rb, int wave, int wm0, int wn0, uint32_t off1, uint32_t off2,
-                               int rot, f32x4 (&acc)[C::TN][C::TM])
+                               int ks0, int nk, int rot, f32x4 (&acc)[C::TN][C::TM])
 {
-    run_tile<C, SCRUB>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, rot, acc);
+    run_tile<C, SCRUB>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, ks0, nk, rot, acc);
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int PP, int ABL, int KS, int LD>
@@ -474,7 +476,11 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThr
     // ---- XCD-aware, bijective block -> tile map ------------------------
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int wg_all = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    // split-K: the grid is p.split copies of the tile grid, K slice slowest (the workgroups an XCD runs at one
+    // time then share one K range of A and B)
+    const int n_tiles = tiles_m * tiles_n;
+    const int kslice = wg_all / n_tiles, wg = wg_all - kslice * n_tiles;
     // Grouped order: kGroupM m-tiles x all n-tiles per group, m fastest inside a group.  The 32 tiles an XCD
     // runs at one time then form a 4 x 8 block whose A and B panels share its 4 MiB L2, instead of 16 x 2
     // (all of A per round): M=N=K=8192 bf16 492 -> 454 us, FLUX and the 128x128 shard -1..2 %.
@@ -522,10 +528,13 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThr
     const uint32_t off2 = (uint32_t)(fr * BK + (((4 + fg) ^ (fr >> 1)) << 4));
 
     const int nk_all = (int)((p.K + BK * C::KS - 1) / (BK * C::KS));
-    const int rot = (int)(((int64_t)tile_m * nk_all) / tiles_m);  // in [0, nk)
+    const int nsplit = p.split > 1 ? p.split : 1;
+    const int nk_slice = (nk_all + nsplit - 1) / nsplit;           // the host made every slice non-empty
+    const int ks0 = kslice * nk_slice, nk = min(nk_slice, nk_all - ks0);
+    const int rot = (int)(((int64_t)tile_m * nk) / tiles_m);       // in [0, nk)
 
     f32x4 acc[C::TN][C::TM];
-    run_tile_any<C, false>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, rot, acc);
+    run_tile_any<C, false>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, ks0, nk, rot, acc);
 
     if (p.nan_zero) {
         int bad = 0;
@@ -543,7 +552,50 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThr
         __syncthreads();
         const int any_bad = *flag;
         __syncthreads();
-        if (any_bad) run_tile_any<C, true>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, rot, acc);
+        if (any_bad) run_tile_any<C, true>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, ks0, nk, rot, acc);
+    }
+
+    // ---- split-K: exchange fp32 partial tiles through the workspace; the LAST workgroup of a tile to arrive
+    //      adds all slices in slice order (its own included, re-read like the others: the sum does not depend
+    //      on who arrived last, results are reproducible run to run) and runs the epilogue.  Nobody waits.
+    if (nsplit > 1) {
+        // Partials cross XCDs (each has its own L2), so they are written and read with sc0 sc1 (system-coherent:
+        // write-through / miss-always) accesses instead of being published with __threadfence(): the fence is a
+        // whole-L2 write-back + invalidate per wave, which cost 40-60 us per launch here.
+        constexpr int kCoherent = 17;  // aux bits: sc0 | sc1
+        int *counters = (int *)p.ws;
+        constexpr int kVecPerWg = C::TN * C::TM * C::kThreads;      // f32x4 per partial tile (register order)
+        __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(p.ws + kWsCounterBytes), 0, (int)min(p.ws_bytes - kWsCounterBytes, (int64_t)0x7FFFFFFF), 0x00020000);
+        const uint32_t slice_bytes = (uint32_t)n_tiles * kVecPerWg * 16u;
+        const uint32_t my_off = ((uint32_t)wg * kVecPerWg + threadIdx.x) * 16u;  // launch() keeps all offsets < 2^31
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[tn][tm]), rw,
+                                                       (int)(my_off + (tn * C::TM + tm) * C::kThreads * 16u),
+                                                       (int)((uint32_t)kslice * slice_bytes), kCoherent);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's partial has reached memory ...
+        volatile int *flag = (volatile int *)smem;
+        __syncthreads();  // ... and so has every other thread's, before the workgroup's arrival is counted
+        if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(&counters[wg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __syncthreads();
+        const int arrived = *flag;
+        if (arrived != nsplit - 1) return;  // workgroup-uniform; nobody waits for anybody
+        for (int s2 = 0; s2 < nsplit; ++s2) {
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < C::TM; ++tm) {
+                    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(
+                        rw, (int)(my_off + (tn * C::TM + tm) * C::kThreads * 16u), (int)((uint32_t)s2 * slice_bytes), kCoherent);
+                    const f32x4 v = __builtin_bit_cast(f32x4, raw);
+                    acc[tn][tm] = s2 == 0 ? v : acc[tn][tm] + v;
+                }
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(&counters[wg], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // zero for the next launch
+        __syncthreads();  // the flag word is part of the ring the staged epilogue reuses
     }
 
     STAMP(k1_);
@@ -568,15 +620,37 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThr
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int PP = 0, int ABL = 0, int KS = 1, int LD = 0>
-int launch(const MMParams &p, hipStream_t s)
+int launch(const MMParams &p_in, hipStream_t s)
 {
     using C = Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>;
+    MMParams p = p_in;
     const int64_t tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     if (tm * tn > 0x7FFFFFFF) return FP8MI_E_UNSUPPORTED;
+    {   // split-K: clamp to what K and the workspace allow; every slice gets at least one ring stage
+        const int64_t nk_all = (p.K + BK * C::KS - 1) / (BK * C::KS);
+        int64_t split = p.split > 1 ? p.split : 1;
+        if (p.split == 0 && tm * tn <= 128 && nk_all >= 8) {
+            // auto: the tile grid leaves at least half of the 256 CUs idle and K is deep - slice K so that the
+            // grid fills the chip, at least 4 ring stages per slice (measured: M=128 K=14336 N=4096 49 -> ~20 us)
+            split = 256 / (tm * tn);
+            if (split > nk_all / 4) split = nk_all / 4;
+            if (split > 16) split = 16;
+        }
+        if (!p.ws || tm * tn > kWsCounterBytes / 4) split = 1;
+        if (split > nk_all) split = nk_all > 0 ? nk_all : 1;
+        if (split > 1) {
+            const int64_t per = (nk_all + split - 1) / split;
+            split = (nk_all + per - 1) / per;  // drop empty slices (the kernel re-derives `per` from this count)
+            if (tm * tn * split > 0x7FFFFFFF) return FP8MI_E_UNSUPPORTED;
+            const int64_t need = kWsCounterBytes + split * tm * tn * (int64_t)BM * BN * 4;
+            if (need > p.ws_bytes || need > 0x7FFFFFFF) split = 1;  // (the kernel addresses partials with 32-bit offsets)
+        }
+        p.split = (int)split;
+    }
     const int esz = p.out_dtype == FP8MI_F32 ? 4 : 2;
     // 16-byte aligned rows and 4-element groups: enables the vector stores of both epilogues
     const int vec = (((p.ldc * esz) % 16) == 0 && (((uintptr_t)p.C) % 16) == 0) ? 1 : 0;
-    FP8MI_LAUNCH((gemm_kernel<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>), dim3((unsigned)(tm * tn)), dim3(C::kThreads), s, p, (int)tm,
+    FP8MI_LAUNCH((gemm_kernel<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>), dim3((unsigned)(tm * tn * p.split)), dim3(C::kThreads), s, p, (int)tm,
                        (int)tn, vec);
     return (int)hipGetLastError();
 }
@@ -607,12 +681,15 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
         const int64_t t128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
         if (t256 >= 192) variant = FP8MI_KERNEL_GEMM_256;
         else if (t128 >= 192) variant = FP8MI_KERNEL_GEMM_128;
+        else if (p.M <= 64 && p.ws && p.split != 1) variant = FP8MI_KERNEL_GEMM_64x128;  // few rows of A and split-K
+                                                                     // to fill the chip: spend the tile on N
         else variant = FP8MI_KERNEL_GEMM_128x64;
     }
     switch (variant) {
     case FP8MI_KERNEL_GEMM_128: return launch<128, 128, 64, 32, 2, 0, 0, 1, 4>(p, s);  // 8 waves (0-3 load), 2 x 32 KiB: 2 workgroups / CU
     case FP8MI_KERNEL_GEMM_128x64: return launch<128, 64, 32, 32, 3, 0, 0, 2, 4>(p, s);  // 8 waves (0-3 load), 3 x 48 KiB ring, 2 K-steps per stage
     case FP8MI_KERNEL_GEMM_256: return launch<256, 256, 128, 64, 2, 0, 0, 1, 4>(p, s);  // 8 waves (0-3 load), 2 x 64 KiB
+    case FP8MI_KERNEL_GEMM_64x128: return launch<64, 128, 32, 32, 3, 0, 0, 2, 4>(p, s);  // 8 waves (0-3 load), 3 x 48 KiB, for M <= 64
     // schedule variants kept for A/B timing (same results): tools/bq.sh <workload> <id>
     case 7: return launch<128, 64, 64, 32, 6>(p, s);                           // 128x64, 4 waves
     case 8: return launch<128, 128, 64, 64, 4>(p, s);                          // 128x128, 4 waves, 4-stage ring

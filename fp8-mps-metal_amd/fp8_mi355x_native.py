@@ -51,6 +51,21 @@ def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# split-K workspaces: one per (device, stream) - launches on one stream are ordered, so they can share it; the
+# counters at its head are zeroed once here and left zero by every launch (include/fp8mi.h).  Kept alive for the
+# life of the process, so a pointer captured into a HIP graph stays valid.
+_workspaces: dict = {}
+
+
+def _workspace(device):
+    key = (device.index, _stream(device))
+    ws = _workspaces.get(key)
+    if ws is None:
+        ws = torch.zeros(int(_l.load().fp8mi_scaled_mm_workspace_bytes()), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
 def _to_device(t: torch.Tensor) -> torch.Tensor:
     return t if t.device.type == DEVICE_TYPE else t.to(DEVICE_TYPE)
 
@@ -69,7 +84,7 @@ def _scale_arg(scale, device, rows: int, what: str):
 def fp8_scaled_mm(A: torch.Tensor, B: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,
                   *, bias: torch.Tensor | None = None, scale_result: torch.Tensor | None = None,
                   out_dtype: torch.dtype | None = None, nan_mode: int | None = None,
-                  kernel: int = _l.KERNEL_AUTO) -> torch.Tensor:
+                  kernel: int = _l.KERNEL_AUTO, split_k: int = 0) -> torch.Tensor:
     """FP8 scaled matrix multiplication on the GPU.
 
     A: (M, K) uint8 - e4m3fn bytes, row-major
@@ -80,6 +95,8 @@ def fp8_scaled_mm(A: torch.Tensor, B: torch.Tensor, scale_a: torch.Tensor, scale
         ((A_dec @ B_dec.T) * scale_a * scale_b + bias) * scale_result
     Same contract as fp8_mps_native.py:41-95 (asserts included); the kernel is
     picked by shape inside the library (GEMV for M == 1, MFMA GEMM otherwise).
+    split_k: 0 lets the library slice K when M x N gives too few tiles to fill
+    the GPU (small batch, deep K), 1 forbids it, > 1 forces that many slices.
     """
     assert A.dtype == torch.uint8 and B.dtype == torch.uint8
     assert A.dim() == 2 and B.dim() == 2
@@ -125,10 +142,13 @@ def fp8_scaled_mm(A: torch.Tensor, B: torch.Tensor, scale_a: torch.Tensor, scale
 
     lib = _l.load()
     with torch.cuda.device(dev):
-        rc = lib.fp8mi_scaled_mm_ex(
+        # a workspace only where split-K can apply: more than one row, K deep enough to slice
+        ws = _workspace(dev) if (split_k != 1 and M > 1 and K >= 1024) else None
+        rc = lib.fp8mi_scaled_mm_ws(
             A.data_ptr(), B.data_ptr(), C.data_ptr(), sa.data_ptr(), sb.data_ptr(), bias_ptr, sr_ptr,
             M, N, K, lda, ldb, N, sa_mode, sb_mode, _DTYPE_CODE[out_dtype], bias_code,
-            NAN_MODE if nan_mode is None else nan_mode, kernel, _stream(dev))
+            NAN_MODE if nan_mode is None else nan_mode, kernel, split_k if ws is not None else 1,
+            ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream(dev))
     _l.check(rc, "fp8mi_scaled_mm")
     return C
 

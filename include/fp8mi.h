@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FP8MI_VERSION 0x000100 /* 0.1.0 */
+#define FP8MI_VERSION 0x000200 /* 0.2.0: + split-K workspace entry point */
 
 /* element types of non-fp8 operands */
 enum { FP8MI_F32 = 0, FP8MI_F16 = 1, FP8MI_BF16 = 2 };
@@ -61,8 +61,9 @@ enum { FP8MI_KERNEL_AUTO = 0,
        FP8MI_KERNEL_GENERIC = 3,   /* any shape / alignment, one wave per output      */
        FP8MI_KERNEL_GEMM_256 = 4,  /* 256x256x128 LDS-tiled fp8 MFMA (large M,N)      */
        FP8MI_KERNEL_GEMM_128x64 = 5, /* 128x64x128 tile (few tiles: one per CU)       */
-       FP8MI_KERNEL_SKINNY = 6 };  /* 1 <= M <= 64 weight-streaming MFMA              */
-/* ids >= 7 select experimental schedule variants of the tile kernel (see
+       FP8MI_KERNEL_SKINNY = 6,    /* 1 <= M <= 64 weight-streaming MFMA              */
+       FP8MI_KERNEL_GEMM_64x128 = 14 }; /* 64x128x128 tile (M <= 64, deep K)          */
+/* ids 7..13 select experimental schedule variants of the tile kernel (see
  * fp8mi_gemm.hip); they compute the same result and exist for A/B timing. */
 
 /* error codes (negative returns) */
@@ -111,6 +112,41 @@ int fp8mi_scaled_mm_ex(const uint8_t *A, const uint8_t *B_nk, void *C,
                        int scale_a_mode, int scale_b_mode,
                        int out_dtype, int bias_dtype, int nan_mode,
                        int kernel, void *stream);
+
+/*
+ * Split-K.  When M x N yields far fewer output tiles than the 256 CUs (small M,
+ * deep K: the decode / small-batch regime) the tile kernels can cut K into
+ * `split_k` slices, one workgroup per (tile, slice); the slices' fp32 partial
+ * tiles meet in `workspace`, and the last workgroup of a tile to finish adds
+ * them in slice order (run-to-run reproducible) and runs the fused epilogue.
+ * No counterpart in the reference (its kernels are one thread per output,
+ * fp8_matmul.metal:99-147).
+ *
+ * workspace        device buffer, 16-byte aligned, used by ONE launch at a time
+ *                  (launches on one stream may share it; concurrent streams
+ *                  need their own).  Its first FP8MI_WS_COUNTER_BYTES bytes
+ *                  must be zero before the first launch that uses it; every
+ *                  launch leaves them zero.  NULL: never split.
+ * workspace_bytes  its size; fp8mi_scaled_mm_workspace_bytes() is enough for
+ *                  every problem the library would split on its own.  A
+ *                  workspace that is too small silently disables the split.
+ * split_k          0: library decides; 1: no split; > 1: that many slices
+ *                  (clamped to what K and the workspace allow).
+ * fp8mi_scaled_mm / _ex are this call with workspace == NULL.
+ */
+#define FP8MI_WS_COUNTER_BYTES 4096
+int64_t fp8mi_scaled_mm_workspace_bytes(void);
+int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C,
+                       const float *scale_a, const float *scale_b,
+                       const void *bias, const float *scale_result,
+                       int64_t M, int64_t N, int64_t K,
+                       int64_t lda, int64_t ldb, int64_t ldc,
+                       int scale_a_mode, int scale_b_mode,
+                       int out_dtype, int bias_dtype, int nan_mode,
+                       int kernel, int split_k,
+                       void *workspace, int64_t workspace_bytes,
+                       void *stream);
+
 
 /*
  * out[i] = cast( half(dec(in[i])) * half(scale) )      (scale NULL = no multiply)

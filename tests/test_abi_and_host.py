@@ -42,7 +42,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_argument_errors_without_gpu(lib):
-    assert lib.fp8mi_version() == 0x000100
+    assert lib.fp8mi_version() == 0x000200
     # argument validation happens before any HIP call, so it is testable here
     rc = lib.fp8mi_scaled_mm(None, None, None, None, None, None, None, 4, 4, 4, 4, 4, 4, 0, 0, 0, 0, 0, None)
     assert rc == -1 and b"NULL" in lib.fp8mi_last_error()
@@ -57,6 +57,11 @@ def test_version_and_argument_errors_without_gpu(lib):
     assert lib.fp8mi_dequant(None, None, None, 5, 0, None) == -1
     assert lib.fp8mi_encode(one, 9, one, None, 5, 0, None) == -3
     assert lib.fp8mi_scaled_mm(None, None, None, None, None, None, None, 0, 4, 4, 4, 4, 4, 0, 0, 0, 0, 0, None) == 0
+    # split-K entry point: same validation; split_k < 0 is an enum error; the workspace size is a constant
+    assert lib.fp8mi_scaled_mm_ws(one, one, one, one, one, None, None, -1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, None, 0, None) == -2
+    rc = lib.fp8mi_scaled_mm_ws(one, one, one, one, one, None, None, 4, 4, 16, 16, 16, 4, 0, 0, 0, 0, 0, 0, -1, None, 0, None)
+    assert rc == -3 and b"split_k" in lib.fp8mi_last_error()
+    assert lib.fp8mi_scaled_mm_workspace_bytes() >= 4096 + 256 * 128 * 64 * 4
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -54,7 +54,7 @@ def uses_mfma(kernel, M, K):
 
 
 def check_mm(oracle, native, cuda, A, B, sa, sb, *, kernel=L.KERNEL_AUTO, bias=None, scale_result=None,
-             out_dtype=None, nan_mode=None, tol=None):
+             out_dtype=None, nan_mode=None, tol=None, split_k=0):
     mfma = uses_mfma(kernel, A.shape[0], A.shape[1])
     if tol is None:
         tol = MFMA_TOL if mfma else MM_TOL
@@ -65,7 +65,7 @@ def check_mm(oracle, native, cuda, A, B, sa, sb, *, kernel=L.KERNEL_AUTO, bias=N
         kw["scale_result"] = dev(np.array([scale_result], np.float32), cuda)
     got = native.fp8_scaled_mm(dev(A, cuda), dev(B, cuda), dev(np.asarray(sa, np.float32), cuda),
                                dev(np.asarray(sb, np.float32), cuda), out_dtype=out_dtype, kernel=kernel,
-                               nan_mode=nan_mode, **kw)
+                               nan_mode=nan_mode, split_k=split_k, **kw)
     torch.cuda.synchronize()
     assert got.shape == (A.shape[0], B.shape[0])
     assert got.dtype == (out_dtype or torch.float32)
@@ -461,6 +461,99 @@ def test_full_tile_staged_epilogue(native, cuda, oracle, kernel, out_dtype):
     check_mm(oracle, native, cuda, A, B, sa, sb, kernel=kernel, bias=bias, scale_result=0.25, out_dtype=out_dtype)
 
 
+# ---------------------------------------------------------------------------
+# split-K (no counterpart in the reference: include/fp8mi.h, fp8mi_scaled_mm_ws)
+# ---------------------------------------------------------------------------
+def _counters_zero(native, cuda):
+    ws = native._workspace(cuda)
+    torch.cuda.synchronize()
+    return int(ws[:L.WS_COUNTER_BYTES].view(torch.int32).abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("M,K,N,kernel,split", [
+    (128, 4096, 512, L.KERNEL_GEMM_128x64, 4), (64, 2048, 256, L.KERNEL_GEMM_64x128, 0),
+    (100, 2992, 200, L.KERNEL_GEMM_128x64, 3),     # ragged tile, K tail in the last slice
+    (40, 1040, 130, L.KERNEL_GEMM_64x128, 5),      # more slices asked for than K has ring stages of 256 B
+    (130, 4096, 70, L.KERNEL_GEMM_128x64, 16), (256, 4096, 1024, L.KERNEL_AUTO, 0),
+    (300, 2048, 300, L.KERNEL_GEMM_128, 2), (512, 1024, 512, L.KERNEL_GEMM_256, 2),
+    (16, 8192, 4096, L.KERNEL_AUTO, 0),            # M <= 32 with a large weight matrix: auto leaves the skinny kernel
+    (33, 14336, 512, L.KERNEL_AUTO, 0)])
+def test_split_k_parity_and_reproducibility(native, cuda, oracle, M, K, N, kernel, split):
+    """K cut into slices, fp32 partial tiles summed in slice order by the last workgroup of each tile:
+    parity with the oracle, bit-identical from run to run, and the tile counters are left zero."""
+    rng = np.random.default_rng(M + K + N + split)
+    A, B = clean_bytes(rng, (M, K)), clean_bytes(rng, (N, K))
+    sa = rng.uniform(0.005, 0.02, size=M).astype(np.float32)
+    sb = rng.uniform(0.005, 0.02, size=N).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    for od in (torch.float32, torch.bfloat16):
+        got = check_mm(oracle, native, cuda, A, B, sa, sb, kernel=kernel, bias=bias, out_dtype=od, split_k=split,
+                       tol=MFMA_TOL)
+        again = native.fp8_scaled_mm(dev(A, cuda), dev(B, cuda), dev(sa, cuda), dev(sb, cuda), bias=dev(bias, cuda),
+                                     out_dtype=od, kernel=kernel, split_k=split)
+        assert torch.equal(got, again)
+    assert _counters_zero(native, cuda)
+
+
+def test_split_k_nan_modes(native, cuda, oracle):
+    """A NaN byte inside one K slice: reference mode redoes only that slice's partial with the scrub;
+    OCP mode poisons the row / column through the partial sum."""
+    rng = np.random.default_rng(77)
+    A, B = clean_bytes(rng, (96, 2048)), clean_bytes(rng, (160, 2048))
+    A[3, 1500] = 0x7F
+    B[5, 10] = 0xFF
+    check_mm(oracle, native, cuda, A, B, [1.0], [1.0], kernel=L.KERNEL_GEMM_128x64, split_k=4)
+    got = native.fp8_scaled_mm(dev(A, cuda), dev(B, cuda), torch.ones(1), torch.ones(1), kernel=L.KERNEL_GEMM_128x64,
+                               nan_mode=L.NAN_PROPAGATE, split_k=4).cpu().numpy()
+    nan = np.isnan(got)
+    assert nan[3, :].all() and nan[:, 5].all() and nan.sum() == 160 + 96 - 1
+    assert _counters_zero(native, cuda)
+
+
+def test_split_k_workspace_contract(native, cuda, oracle):
+    """C ABI: a missing, misaligned or too-small workspace silently disables the split (same bits as split_k = 1);
+    split_k < 0 is an argument error; the advertised size covers the library's own choices."""
+    lib = L.load()
+    assert lib.fp8mi_scaled_mm_workspace_bytes() >= L.WS_COUNTER_BYTES + 256 * 128 * 64 * 4
+    rng = np.random.default_rng(78)
+    M, K, N = 128, 4096, 256
+    A, B = dev(clean_bytes(rng, (M, K)), cuda), dev(clean_bytes(rng, (N, K)), cuda)
+    s1 = torch.full((1,), 0.01, device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(ws_ptr, ws_bytes, split):
+        C = torch.empty(M, N, device=cuda)
+        rc = lib.fp8mi_scaled_mm_ws(A.data_ptr(), B.data_ptr(), C.data_ptr(), s1.data_ptr(), s1.data_ptr(), None, None,
+                                    M, N, K, K, K, N, 0, 0, L.F32, 0, 0, L.KERNEL_GEMM_128x64, split, ws_ptr, ws_bytes, st)
+        torch.cuda.synchronize()
+        return rc, C
+
+    ws = torch.zeros(int(lib.fp8mi_scaled_mm_workspace_bytes()), dtype=torch.uint8, device=cuda)
+    rc, base = run(None, 0, 1)
+    assert rc == 0
+    rc, split = run(ws.data_ptr(), ws.numel(), 4)
+    assert rc == 0 and not torch.equal(split, base)            # really took the split path (different summation order)
+    assert torch.allclose(split, base, rtol=0, atol=2e-3 * float(base.abs().max()))
+    for ptr, nbytes in ((None, 0), (ws.data_ptr() + 4, ws.numel() - 4), (ws.data_ptr(), L.WS_COUNTER_BYTES + 1024),
+                        (ws.data_ptr(), 16)):
+        rc, c = run(ptr, nbytes, 4)
+        assert rc == 0 and torch.equal(c, base)
+    rc, _ = run(ws.data_ptr(), ws.numel(), -1)
+    assert rc == -3 and b"split_k" in lib.fp8mi_last_error()
+    assert int(ws[:L.WS_COUNTER_BYTES].view(torch.int32).abs().sum().item()) == 0
+
+
+def test_split_k_full_size_decode_shape(native, cuda, oracle):
+    """M = 64 rows against a 14336 x 4096 weight matrix (the C2 weight shape with a small batch):
+    auto dispatch slices K; checked against the C oracle in float64."""
+    rng = np.random.default_rng(79)
+    A, B = clean_bytes(rng, (64, 14336)), clean_bytes(rng, (4096, 14336))
+    got = check_mm(oracle, native, cuda, A, B, [0.01], [0.02], out_dtype=torch.float32)
+    one = native.fp8_scaled_mm(dev(A, cuda), dev(B, cuda), torch.full((1,), 0.01), torch.full((1,), 0.02), split_k=1)
+    assert not torch.equal(got, one)  # the auto path did split
+    assert _counters_zero(native, cuda)
+
+
 def test_graph_capture_of_the_c_abi(native, cuda, oracle):
     """Entry points only enqueue (no sync, no allocation): capturable in a HIP graph."""
     rng = np.random.default_rng(56)
@@ -475,14 +568,20 @@ def test_graph_capture_of_the_c_abi(native, cuda, oracle):
         native.fp8_quantize(x)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
+    A2, B2 = clean_bytes(rng, (64, 4096)), clean_bytes(rng, (256, 4096))   # split-K path (workspace + counters)
+    a2, b2 = dev(A2, cuda), dev(B2, cuda)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         c = native.fp8_scaled_mm(a, b, s1, s1)
+        c2 = native.fp8_scaled_mm(a2, b2, s1, s1)
         q, inv = native.fp8_quantize(x)
         h = native.fp8_dequantize(q, inv)
-    c.zero_(); q.zero_()
+    c.zero_(); q.zero_(); c2.zero_()
+    g.replay()
     g.replay()
     torch.cuda.synchronize()
+    exact2 = oracle.scaled_mm(A2, B2, [0.5], [0.5], accumulate="f64")
+    assert np.all(np.abs(c2.cpu().numpy() - exact2) <= MFMA_TOL * oracle.abs_dot_bound(A2, B2, [0.5], [0.5]))
     exact = oracle.scaled_mm(A, B, [0.5], [0.5], accumulate="f64")
     assert np.all(np.abs(c.cpu().numpy() - exact) <= MFMA_TOL * oracle.abs_dot_bound(A, B, [0.5], [0.5]))
     eq, einv = oracle.quantize(x.cpu().numpy())
