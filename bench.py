@@ -88,6 +88,11 @@ def clean_bytes(shape, dev, gen):
     return out.reshape(shape)
 
 
+# name -> (M, K, N); "decode" = a small batch against the C2 weight shape (split-K fills the chip)
+MM_WORKLOADS = {"gemm": (512, 4096, 4096), "gemv": (1, 14336, 4096), "flux": (4096, 3072, 12288),
+                "skinny": (4, 4096, 4096), "decode": (64, 14336, 4096)}
+
+
 class Workload:
     """One named workload: buffers + a `launch(i)` closure calling the C ABI."""
 
@@ -97,15 +102,14 @@ class Workload:
         self.lib = L.load()
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)
         self.collective = None
-        if name in ("gemm", "gemv", "flux", "skinny"):
-            M, K, N = {"gemm": (512, 4096, 4096), "gemv": (1, 14336, 4096), "flux": (4096, 3072, 12288),
-                       "skinny": (4, 4096, 4096)}[name]
+        if name in MM_WORKLOADS:
+            M, K, N = MM_WORKLOADS[name]
             self.M, self.K, self.N_total = M, K, N
             Nl = N // world
             assert N % world == 0
             self.N = Nl
-            self.out_dtype = torch.bfloat16 if name == "flux" else torch.float32
-            esz = 2 if name == "flux" else 4
+            self.out_dtype = torch.bfloat16 if name in ("flux", "decode") else torch.float32
+            esz = 2 if name in ("flux", "decode") else 4
             nbuf = nbuf or max(2, -(-int(1.25 * CACHE_BYTES) // (Nl * K)))
             self.A = clean_bytes((M, K), dev, torch.Generator(device=dev).manual_seed(99))  # replicated activations
             self.Bs = [clean_bytes((Nl, K), dev, gen) for _ in range(nbuf)]
@@ -113,7 +117,9 @@ class Workload:
             self.sb = torch.full((1,), 0.01, dtype=torch.float32, device=dev)
             self.flops = 2.0 * M * Nl * K
             self.bytes = float(M * K + Nl * K + esz * M * Nl)
-            self.unit_flops = name not in ("gemv", "skinny")   # weight-streaming shapes are quoted in GB/s
+            self.unit_flops = name not in ("gemv", "skinny", "decode")   # weight-streaming shapes are quoted in GB/s
+            # split-K workspace (include/fp8mi.h): owned by the caller, counter block zeroed once
+            self.ws = torch.zeros(int(self.lib.fp8mi_scaled_mm_workspace_bytes()), dtype=torch.uint8, device=dev)
             self.inner = nbuf * (4 if name == "gemv" else 1)
             if self.sharded:
                 # the shipped N-column-sharded linear (fp8_sharded_linear.py): transposed blocks,
@@ -125,9 +131,9 @@ class Workload:
                 self.Cs = [torch.empty(Nl, M, dtype=self.out_dtype, device=dev) for _ in range(2)]
             else:
                 self.Cs = [torch.empty(M, Nl, dtype=self.out_dtype, device=dev) for _ in range(2)]
-            self.code = L.BF16 if name == "flux" else L.F32
+            self.code = L.BF16 if name in ("flux", "decode") else L.F32
             self.desc = {"workload": f"{name}: M={M} K={K} N={N} e4m3fn, per-tensor scales, "
-                                     f"{'bf16' if name == 'flux' else 'fp32'} out, {nbuf} rotating weight buffers",
+                                     f"{'bf16' if name in ('flux', 'decode') else 'fp32'} out, {nbuf} rotating weight buffers",
                          "M": M, "K": K, "N": N}
         elif name in ("quantize", "dequant"):
             n = 1 << 30
@@ -150,17 +156,19 @@ class Workload:
 
     def launch(self, i, stream):
         lib = self.lib
-        if self.name in ("gemm", "gemv", "flux", "skinny"):
+        if self.name in MM_WORKLOADS:
             B = self.Bs[i % len(self.Bs)]
             C = self.Cs[i % 2]
             if self.world > 1:  # transposed product: "A" operand = weight shard, "B_nk" operand = activations
-                rc = lib.fp8mi_scaled_mm_ex(B.data_ptr(), self.A.data_ptr(), C.data_ptr(), self.sb.data_ptr(),
+                rc = lib.fp8mi_scaled_mm_ws(B.data_ptr(), self.A.data_ptr(), C.data_ptr(), self.sb.data_ptr(),
                                             self.sa.data_ptr(), None, None, self.N, self.M, self.K, self.K, self.K,
-                                            self.M, 0, 0, self.code, 0, L.NAN_ZERO, self.kernel, stream)
+                                            self.M, 0, 0, self.code, 0, L.NAN_ZERO, self.kernel, 0,
+                                            self.ws.data_ptr(), self.ws.numel(), stream)
             else:
-                rc = lib.fp8mi_scaled_mm_ex(self.A.data_ptr(), B.data_ptr(), C.data_ptr(), self.sa.data_ptr(),
+                rc = lib.fp8mi_scaled_mm_ws(self.A.data_ptr(), B.data_ptr(), C.data_ptr(), self.sa.data_ptr(),
                                             self.sb.data_ptr(), None, None, self.M, self.N, self.K, self.K, self.K,
-                                            self.N, 0, 0, self.code, 0, L.NAN_ZERO, self.kernel, stream)
+                                            self.N, 0, 0, self.code, 0, L.NAN_ZERO, self.kernel, 0,
+                                            self.ws.data_ptr(), self.ws.numel(), stream)
         elif self.name == "quantize":
             rc = lib.fp8mi_encode(self.src[0].data_ptr(), L.F32, self.dst[0].data_ptr(), None, self.count,
                                   L.ENC_REFERENCE, stream)
@@ -259,7 +267,7 @@ def cpu_baseline(w, budget_s=12.0):
     vp, sz = ctypes.c_void_p, ctypes.c_size_t
     import numpy as np
     rng = np.random.default_rng(1234)
-    if w.name in ("gemm", "gemv", "flux", "skinny"):
+    if w.name in MM_WORKLOADS:
         K, N = w.K, min(w.N_total, 4096)
         B = rng.integers(0, 127, size=(N, K), dtype=np.uint8)
         sa = np.array([0.01], np.float32)
@@ -338,7 +346,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="auto", choices=["auto", "gemm", "gemv", "flux", "skinny", "quantize", "dequant"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "gemm", "gemv", "flux", "skinny", "decode", "quantize", "dequant"])
     ap.add_argument("--kernel", type=int, default=L.KERNEL_AUTO, help="force an FP8MI_KERNEL_* id")
     ap.add_argument("--nbuf", type=int, default=None, help="override the number of rotating weight buffers "
                     "(1 = weights stay cache-resident; for sensitivity experiments only)")
@@ -383,7 +391,7 @@ def main():
         "metric": METRIC, "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
         "scaling": "strong" if primary == "flux" else "weak", "vs_baseline": None,
-        "dtype": "fp8_e4m3fn (fp32 accumulate)" if primary in ("gemm", "gemv", "flux", "skinny") else "u8",
+        "dtype": "fp8_e4m3fn (fp32 accumulate)" if primary in MM_WORKLOADS else "u8",
         "data": {"gauss": "synthetic (seeded N(0,1) amax-quantised to e4m3fn; weights rotate through > 256 MiB)",
                  "uniform": "synthetic (seeded uniform e4m3 bytes, NaN patterns remapped; weights rotate through > 256 MiB)",
                  "zeros": "synthetic (all-zero bytes; clock upper bound, not a reportable number)"}[args.data],
@@ -398,7 +406,7 @@ def main():
 
     if world == 1 and args.workload == "auto" and not args.no_secondary and not args.force_sharded:
         sec = {}
-        for name in ("gemv", "flux", "skinny", "quantize", "dequant"):
+        for name in ("gemv", "flux", "skinny", "decode", "quantize", "dequant"):
             try:
                 r = measure(name, dev, max(3, args.steps // 2), max(1, args.warmup // 2), 1, 0, L.KERNEL_AUTO,
                             with_cpu=(name == "gemv" and not args.no_cpu_baseline), info=info)

@@ -27,7 +27,7 @@ void fp8o_decode_lut(float *out256);
 static uint32_t rng = 12345u;
 static uint32_t next(void) { rng = rng * 1664525u + 1013904223u; return rng >> 8; }
 
-static int run_mm(int M, int K, int N, double tol)
+static int run_mm(int M, int K, int N, double tol, int split_k)
 {
     uint8_t *A = malloc((size_t)M * K), *B = malloc((size_t)N * K);
     for (size_t i = 0; i < (size_t)M * K; ++i) A[i] = (uint8_t)next();   /* NaN bytes included: reference mode */
@@ -41,8 +41,18 @@ static int run_mm(int M, int K, int N, double tol)
     CHECK_HIP(hipMalloc((void **)&dsa, 4 * M)); CHECK_HIP(hipMalloc((void **)&dsb, 4 * N));
     CHECK_HIP(hipMemcpy(dA, A, (size_t)M * K, hipMemcpyHostToDevice)); CHECK_HIP(hipMemcpy(dB, B, (size_t)N * K, hipMemcpyHostToDevice));
     CHECK_HIP(hipMemcpy(dsa, sa, 4 * M, hipMemcpyHostToDevice)); CHECK_HIP(hipMemcpy(dsb, sb, 4 * N, hipMemcpyHostToDevice));
-    CHECK_MI(fp8mi_scaled_mm(dA, dB, dC, dsa, dsb, NULL, NULL, M, N, K, K, K, N, FP8MI_SCALE_ROW, FP8MI_SCALE_ROW, FP8MI_F32, 0,
-                             FP8MI_NAN_ZERO, NULL));
+    void *ws = NULL; int64_t ws_bytes = 0;
+    if (split_k != 1) {  /* split-K: the host owns the workspace; its counter block starts out zero */
+        ws_bytes = fp8mi_scaled_mm_workspace_bytes();
+        CHECK_HIP(hipMalloc(&ws, (size_t)ws_bytes));
+        CHECK_HIP(hipMemset(ws, 0, FP8MI_WS_COUNTER_BYTES));
+        for (int rep = 0; rep < 2; ++rep)  /* twice: the first launch must leave the counters zero for the second */
+            CHECK_MI(fp8mi_scaled_mm_ws(dA, dB, dC, dsa, dsb, NULL, NULL, M, N, K, K, K, N, FP8MI_SCALE_ROW, FP8MI_SCALE_ROW,
+                                        FP8MI_F32, 0, FP8MI_NAN_ZERO, FP8MI_KERNEL_AUTO, split_k, ws, ws_bytes, NULL));
+    } else {
+        CHECK_MI(fp8mi_scaled_mm(dA, dB, dC, dsa, dsb, NULL, NULL, M, N, K, K, K, N, FP8MI_SCALE_ROW, FP8MI_SCALE_ROW, FP8MI_F32, 0,
+                                 FP8MI_NAN_ZERO, NULL));
+    }
     CHECK_HIP(hipDeviceSynchronize());
     float *C = malloc(sizeof(float) * M * N); double *E = malloc(sizeof(double) * M * N);
     CHECK_HIP(hipMemcpy(C, dC, sizeof(float) * M * N, hipMemcpyDeviceToHost));
@@ -57,7 +67,8 @@ static int run_mm(int M, int K, int N, double tol)
             double r = fabs(C[(size_t)m * N + n] - E[(size_t)m * N + n]) / (bound + 1e-300);
             if (r > worst) worst = r;
         }
-    printf("scaled_mm M=%d K=%d N=%d: max err / sum|ab| = %.3e (tol %.1e)\n", M, K, N, worst, tol);
+    printf("scaled_mm M=%d K=%d N=%d split_k=%d: max err / sum|ab| = %.3e (tol %.1e)\n", M, K, N, split_k, worst, tol);
+    if (ws) hipFree(ws);
     hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dsa); hipFree(dsb); free(A); free(B); free(C); free(E); free(sa); free(sb);
     return worst <= tol ? 0 : 1;
 }
@@ -100,10 +111,12 @@ int main(void)
     printf("error path: \"%s\"\n", fp8mi_last_error());
 
     int rc = 0;
-    rc |= run_mm(1, 2048, 96, 4e-6);      /* GEMV, fp32 VALU */
-    rc |= run_mm(4, 1024, 64, 1e-3);      /* skinny, MFMA */
-    rc |= run_mm(200, 528, 136, 1e-3);    /* tile GEMM, ragged, K tail */
-    rc |= run_mm(3, 100, 7, 4e-6);        /* generic (K % 16 != 0) */
+    rc |= run_mm(1, 2048, 96, 4e-6, 1);      /* GEMV, fp32 VALU */
+    rc |= run_mm(4, 1024, 64, 1e-3, 1);      /* skinny, MFMA */
+    rc |= run_mm(200, 528, 136, 1e-3, 1);    /* tile GEMM, ragged, K tail */
+    rc |= run_mm(3, 100, 7, 4e-6, 1);        /* generic (K % 16 != 0) */
+    rc |= run_mm(96, 4096, 200, 1e-3, 0);    /* tile GEMM, split-K chosen by the library, host-owned workspace */
+    rc |= run_mm(40, 2064, 130, 1e-3, 3);    /* forced 3 slices, K tail in the last one */
     printf(rc ? "FAILED\n" : "C ABI round trip: ok\n");
     return rc;
 }

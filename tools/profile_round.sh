@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$tag; rm -rf $O; mkdir -p $O; cd $R
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python bench.py --steps 10 --warmup 3 > $O/bench_under_rocprof.json 2> $O/kt.err || { echo "kernel-trace run failed"; tail -5 $O/kt.err; exit 1; }
 python tools/summarize_prof.py $O/kt > $O/kernel_trace_summary.txt
-for w in gemm gemv flux skinny quantize dequant; do
+for w in gemm gemv flux skinny decode quantize dequant; do
   n=6; [ $w = quantize ] && n=3; [ $w = dequant ] && n=3
   timeout -k 10 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_$w -o p -- python tools/run_workload.py $w $n > /dev/null 2>&1 || { echo "FETCH pass failed for $w"; exit 1; }
   timeout -k 10 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_$w -o p -- python tools/run_workload.py $w $n > /dev/null 2>&1 || { echo "WRITE pass failed for $w"; exit 1; }
@@ -16,7 +16,7 @@ python - <<PY
 import csv, glob, json, os, collections
 O = "$O"
 out = {}; lines = []
-for w in ("gemm", "gemv", "flux", "skinny", "quantize", "dequant"):
+for w in ("gemm", "gemv", "flux", "skinny", "decode", "quantize", "dequant"):
     vals = {}
     for kind in ("fetch", "write"):
         f = glob.glob(os.path.join(O, f"{kind}_{w}", "**", "*counter_collection.csv"), recursive=True)[0]
