@@ -245,6 +245,9 @@ def roofline_of(w, kd, info, traffic):
         ach = w.bytes / kd["avg_s"] / 1e9
         r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
     r["frac"] = round(r["achieved"] / r["peak"], 4)
+    if w.unit_flops:  # C3 sits at the ridge: also say how far the same launch is from the HBM roof
+        r["hbm_achieved_GBs"] = round(w.bytes / kd["avg_s"] / 1e9, 1)
+        r["hbm_frac"] = round(r["hbm_achieved_GBs"] / HBM_PEAK_GBS, 4)
     # informational: what this part sustains in isolation (profiles/r01_peak_probe.txt):
     # register-only fp8 MFMA loop on weight-like bytes; 4 GiB streaming read
     r["measured_ceiling"] = 4200.0 if w.unit_flops else 5700.0
@@ -322,6 +325,33 @@ def load_traffic(name):
         return None
 
 
+def allgather_only(w, reps=10):
+    """The collective of the sharded linear alone (same chunk shapes, same process group): per-rank ingress rate."""
+    try:
+        dev, world = w.dev, dist.get_world_size()
+        nc = w.N // w.chunks
+        part = torch.zeros(nc, w.M, dtype=w.out_dtype, device=dev)
+        block = torch.empty(world * nc, w.M, dtype=w.out_dtype, device=dev)
+        for _ in range(3):
+            dist.all_gather_into_tensor(block, part)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            dist.all_gather_into_tensor(block, part)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        t = torch.tensor([us], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        us = float(t.item())
+        recv = (world - 1) * part.numel() * part.element_size()
+        return {"calls_per_linear": w.chunks, "bytes_received_per_call": recv, "avg_us_per_call": round(us, 2),
+                "ingress_GBs_per_rank": round(recv / (us * 1e-6) / 1e9, 1) if recv else 0.0}
+    except Exception as e:  # never let the extra measurement take the bench line down
+        return {"error": repr(e)}
+
+
 def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info, nbuf=None, sharded=False):
     w = Workload(name, dev, world, rank, kernel, nbuf, sharded)
     dt, graphed = time_steps(w, steps, warmup, True, world)
@@ -334,6 +364,8 @@ def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info, nbuf=
     res = {"value": round(value, 3), "unit": unit, "ms_per_step": round(dt / steps * 1e3, 5),
            "launches_per_step": w.inner, "hip_graph": graphed, "config": w.desc,
            "roofline": roofline_of(w, kd, info, load_traffic(name))}
+    if w.sharded and dist.is_initialized():
+        res["allgather_only"] = allgather_only(w)   # GEMM-only rate is roofline.achieved, this is the collective
     if with_cpu:
         res["cpu_baseline"] = cpu_baseline(w)
     del w
@@ -401,6 +433,8 @@ def main():
                        device=info["name"], arch=info["arch"], compute_units=info["compute_units"]),
         "roofline": res["roofline"],
     }
+    if "allgather_only" in res:
+        line["allgather_only"] = res["allgather_only"]
     if "cpu_baseline" in res:
         line["cpu_baseline"] = res["cpu_baseline"]
 
