@@ -174,12 +174,13 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     switch (kernel) {
     case FP8MI_KERNEL_AUTO:
         if (fp8mi_gemv_supported(p)) return hip_result(fp8mi_launch_gemv(p, s), "gemv");
-        if (p.M >= 2 && p.M <= 32 && fp8mi_skinny_supported(p)) {
-            // measured (tools/time_shape.py): the weight-streaming skinny kernel wins up to M = 4 and on small
-            // weight matrices (K = N = 4096: 9-10 vs 12-13 us); from M = 8 on large ones the split-K tile kernel
-            // does (M = 32, K = 14336, N = 4096: 19 vs 30 us) - it needs the workspace
-            const bool big = (double)p.N * (double)p.K >= 32.0 * 1048576.0;
-            if (!(p.ws && p.split != 1 && p.M >= 8 && big && fp8mi_gemm_supported(p)))
+        if (p.M >= 2 && p.M <= 48 && fp8mi_skinny_supported(p)) {
+            // measured (tools/sweep_small_m.py): on small weight matrices the weight-streaming skinny kernel wins up
+            // to M = 48 (K = N = 4096: 8.5-11.4 vs 11.4-12.6 us); on large ones (N*K >= 24 MiB) the split-K tile
+            // kernel wins from M = 2 (K = 4096, N = 14336: 13.7 vs 25.4 us; M = 32, K = 14336, N = 4096: 17.7 vs
+            // 28.4 us) - it needs the workspace
+            const bool big = (double)p.N * (double)p.K >= 24.0 * 1048576.0;
+            if (!(p.ws && p.split != 1 && big && fp8mi_gemm_supported(p)))
                 return hip_result(fp8mi_launch_skinny(p, s), "skinny");
         }
         if (K > 0 && fp8mi_gemm_supported(p)) return hip_result(fp8mi_launch_gemm(p, FP8MI_KERNEL_AUTO, s), "gemm");
