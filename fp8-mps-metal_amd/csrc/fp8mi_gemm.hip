@@ -32,13 +32,18 @@
 //     version of this kernel: 49-66 % of wave time parked in waits,
 //     profiles/r01_v1_*).  One barrier per K-step.  (Ping-pong wave groups, an
 //     in-wave software pipeline and interleaved DMA issue were built and
-//     measured too - none beat this loop, see DESIGN.md 5 - and were removed.)
+//     measured too - none beat this loop, see DESIGN.md 6 - and were removed.)
 //   * output orientation: the W fragment is the MFMA "A" operand and the X
 //     fragment the "B" operand, so each lane ends up with 4 CONSECUTIVE n of
 //     one row m in an accumulator register quad -> one 16-byte store.
 //   * the epilogue (scales, bias, result scale, cast) is fused.
 //   * block -> tile mapping is XCD-aware: the 8 XCDs get contiguous runs of
-//     tiles (m fastest) so that the tiles sharing a B panel hit one L2.
+//     tiles in a grouped order (4 m-tiles x all n-tiles per group), so the
+//     tiles an XCD runs at one time share a few A and B panels in its L2.
+//   * split-K (fp8mi_scaled_mm_ws): when the tile grid leaves most CUs idle,
+//     K is cut into slices, one workgroup per (tile, slice); fp32 partial
+//     tiles meet in a caller-owned workspace and the last workgroup of a tile
+//     to arrive adds them in slice order and runs the epilogue.
 //
 // NaN bytes: the hardware treats 0x7F/0xFF as NaN; the reference decodes them
 // to 0.0 (fp8_matmul.metal:21).  The K loop runs unscrubbed; because finite
