@@ -14,6 +14,7 @@ PAD = int(os.environ.get("PAD", "0"))  # extra bytes per row (row stride K + PAD
 LD = K + PAD
 A = torch.randint(0, 120, (M, LD), dtype=torch.uint8, device=dev, generator=g)
 nb = max(2, (320 << 20) // max(N * LD, 1)); nb = min(nb, 24)
+nb = int(os.environ.get("NB", nb))  # NB=1: one weight buffer (cache-resident after the warm-up launches)
 Bs = [torch.randint(0, 120, (N, LD), dtype=torch.uint8, device=dev, generator=g) for _ in range(nb)]
 C = torch.empty(M, N, dtype=torch.float32 if out == "f32" else torch.bfloat16, device=dev)
 s1 = torch.full((1,), 0.01, device=dev)
