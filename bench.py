@@ -135,6 +135,25 @@ class Workload:
             self.desc = {"workload": f"{name}: M={M} K={K} N={N} e4m3fn, per-tensor scales, "
                                      f"{'bf16' if name in ('flux', 'decode') else 'fp32'} out, {nbuf} rotating weight buffers",
                          "M": M, "K": K, "N": N}
+        elif name == "linear":
+            # end-to-end dynamic-quant linear on the FLUX shape: bf16 activations -> amax -> scaled encode -> scaled_mm
+            # with a bf16 result: three launches per linear, no host sync in between
+            M, K, N = MM_WORKLOADS["flux"]
+            self.M, self.K, self.N, self.N_total = M, K, N, N
+            nbuf = nbuf or max(2, -(-int(1.25 * CACHE_BYTES) // (N * K)))
+            self.x = (torch.randn(M, K, device=dev, generator=gen) * 3).to(torch.bfloat16)
+            self.xq = torch.empty(M, K, dtype=torch.uint8, device=dev)
+            self.scales = torch.empty(2, dtype=torch.float32, device=dev)
+            self.Bs = [clean_bytes((N, K), dev, gen) for _ in range(nbuf)]
+            self.sb = torch.full((1,), 0.01, dtype=torch.float32, device=dev)
+            self.Cs = [torch.empty(M, N, dtype=torch.bfloat16, device=dev) for _ in range(2)]
+            self.ws = torch.zeros(int(self.lib.fp8mi_scaled_mm_workspace_bytes()), dtype=torch.uint8, device=dev)
+            self.flops = 2.0 * M * N * K
+            self.bytes = float(2 * M * K * 2 + M * K + M * K + N * K + 2 * M * N)
+            self.unit_flops = True
+            self.inner = nbuf
+            self.desc = {"workload": f"linear: x bf16 ({M},{K}) -> amax + encode -> scaled_mm with W e4m3fn ({N},{K}) -> bf16; "
+                                     f"3 launches per linear, {nbuf} rotating weight buffers", "M": M, "K": K, "N": N}
         elif name in ("quantize", "dequant"):
             n = 1 << 30
             self.count = n
@@ -169,6 +188,14 @@ class Workload:
                                             self.sb.data_ptr(), None, None, self.M, self.N, self.K, self.K, self.K,
                                             self.N, 0, 0, self.code, 0, L.NAN_ZERO, self.kernel, 0,
                                             self.ws.data_ptr(), self.ws.numel(), stream)
+        elif self.name == "linear":
+            rc = lib.fp8mi_quantize(self.x.data_ptr(), L.BF16, self.xq.data_ptr(), self.scales.data_ptr(), self.x.numel(),
+                                    L.ENC_REFERENCE, stream)
+            L.check(rc, "bench launch linear/quantize")
+            rc = lib.fp8mi_scaled_mm_ws(self.xq.data_ptr(), self.Bs[i % len(self.Bs)].data_ptr(), self.Cs[i % 2].data_ptr(),
+                                        self.scales.data_ptr() + 4, self.sb.data_ptr(), None, None, self.M, self.N, self.K,
+                                        self.K, self.K, self.N, 0, 0, L.BF16, 0, L.NAN_ZERO, self.kernel, 0,
+                                        self.ws.data_ptr(), self.ws.numel(), stream)
         elif self.name == "quantize":
             rc = lib.fp8mi_encode(self.src[0].data_ptr(), L.F32, self.dst[0].data_ptr(), None, self.count,
                                   L.ENC_REFERENCE, stream)
@@ -360,7 +387,7 @@ def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info, nbuf=
         value, unit = w.flops * world * launches / dt / 1e12, "TFLOP/s"
     else:
         value, unit = w.bytes * launches / dt / 1e9, "GB/s"
-    kd = kernel_durations(w, min(4 * w.inner, 256)) if world == 1 or True else None
+    kd = kernel_durations(w, min(4 * w.inner, 256)) if name != "linear" else None   # the chain is three kernels
     res = {"value": round(value, 3), "unit": unit, "ms_per_step": round(dt / steps * 1e3, 5),
            "launches_per_step": w.inner, "hip_graph": graphed, "config": w.desc,
            "roofline": roofline_of(w, kd, info, load_traffic(name))}
@@ -378,7 +405,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="auto", choices=["auto", "gemm", "gemv", "flux", "skinny", "decode", "quantize", "dequant"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "gemm", "gemv", "flux", "skinny", "decode", "linear", "quantize", "dequant"])
     ap.add_argument("--kernel", type=int, default=L.KERNEL_AUTO, help="force an FP8MI_KERNEL_* id")
     ap.add_argument("--nbuf", type=int, default=None, help="override the number of rotating weight buffers "
                     "(1 = weights stay cache-resident; for sensitivity experiments only)")
@@ -417,13 +444,13 @@ def main():
         raise SystemExit("multi-GPU runs shard the FLUX linear (configs[3]); use --workload flux or auto")
 
     res = measure(primary, dev, args.steps, args.warmup, world, rank, args.kernel,
-                  with_cpu=(world == 1 and rank == 0 and not args.no_cpu_baseline and not args.force_sharded),
+                  with_cpu=(world == 1 and rank == 0 and not args.no_cpu_baseline and not args.force_sharded and primary != "linear"),
                   info=info, nbuf=args.nbuf, sharded=args.force_sharded)
     line = {
         "metric": METRIC, "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
         "scaling": "strong" if primary == "flux" else "weak", "vs_baseline": None,
-        "dtype": "fp8_e4m3fn (fp32 accumulate)" if primary in MM_WORKLOADS else "u8",
+        "dtype": "fp8_e4m3fn (fp32 accumulate)" if (primary in MM_WORKLOADS or primary == "linear") else "u8",
         "data": {"gauss": "synthetic (seeded N(0,1) amax-quantised to e4m3fn; weights rotate through > 256 MiB)",
                  "uniform": "synthetic (seeded uniform e4m3 bytes, NaN patterns remapped; weights rotate through > 256 MiB)",
                  "zeros": "synthetic (all-zero bytes; clock upper bound, not a reportable number)"}[args.data],
@@ -440,7 +467,7 @@ def main():
 
     if world == 1 and args.workload == "auto" and not args.no_secondary and not args.force_sharded:
         sec = {}
-        for name in ("gemv", "flux", "skinny", "decode", "quantize", "dequant"):
+        for name in ("gemv", "flux", "skinny", "decode", "linear", "quantize", "dequant"):
             try:
                 r = measure(name, dev, max(3, args.steps // 2), max(1, args.warmup // 2), 1, 0, L.KERNEL_AUTO,
                             with_cpu=(name == "gemv" and not args.no_cpu_baseline), info=info)

@@ -226,6 +226,26 @@ def fp8_quantize(input: torch.Tensor, encode_mode: int | None = None):
     return out, scales[1:2]
 
 
+def fp8_linear(x: torch.Tensor, weight_u8: torch.Tensor, weight_scale: torch.Tensor, bias: torch.Tensor | None = None,
+               out_dtype: torch.dtype | None = None) -> torch.Tensor:
+    """y = x @ dequant(W).T + bias with dynamic per-tensor activation quantisation - the composition the reference's
+    call sites perform around its two entry points (fp8_quantize, fp8_mps_native.py:158-190, then torch._scaled_mm
+    through fp8_mps_patch.py:53-106), as one call: amax + scaled encode of x (two launches, no host sync), then the
+    scaled matmul with the fused bias / cast epilogue.
+
+    x: (..., K) float32 / float16 / bfloat16;  weight_u8: (N, K) e4m3fn bytes;  weight_scale: [1] or [N] float32.
+    Returns (..., N) in `out_dtype` (default: x.dtype, float32 for other inputs)."""
+    assert weight_u8.dtype == torch.uint8 and weight_u8.dim() == 2
+    K = weight_u8.shape[1]
+    assert x.shape[-1] == K, f"x has {x.shape[-1]} features; weight expects {K}"
+    x2 = _to_device(x).reshape(-1, K)
+    xq, x_inv_scale = fp8_quantize(x2)
+    if out_dtype is None:
+        out_dtype = x.dtype if x.dtype in _DTYPE_CODE else torch.float32
+    y = fp8_scaled_mm(xq, weight_u8, x_inv_scale, weight_scale, bias=bias, out_dtype=out_dtype)
+    return y.reshape(*x.shape[:-1], weight_u8.shape[0])
+
+
 def fp8_amax(input: torch.Tensor) -> torch.Tensor:
     """max|input| as a float32[1] device tensor (no host sync)."""
     inp = _encode_source(input)
