@@ -88,6 +88,8 @@ def clean_bytes(shape, dev, gen):
     return out.reshape(shape)
 
 
+MAX_STREAMS = 4
+
 # name -> (M, K, N); "decode" = a small batch against the C2 weight shape (split-K fills the chip)
 MM_WORKLOADS = {"gemm": (512, 4096, 4096), "gemv": (1, 14336, 4096), "flux": (4096, 3072, 12288),
                 "skinny": (4, 4096, 4096), "decode": (64, 14336, 4096)}
@@ -118,8 +120,10 @@ class Workload:
             self.flops = 2.0 * M * Nl * K
             self.bytes = float(M * K + Nl * K + esz * M * Nl)
             self.unit_flops = name not in ("gemv", "skinny", "decode")   # weight-streaming shapes are quoted in GB/s
-            # split-K workspace (include/fp8mi.h): owned by the caller, counter block zeroed once
-            self.ws = torch.zeros(int(self.lib.fp8mi_scaled_mm_workspace_bytes()), dtype=torch.uint8, device=dev)
+            # split-K workspaces (include/fp8mi.h): owned by the caller, counter block zeroed once; one per
+            # concurrent launch chain (--streams)
+            self.wss = [torch.zeros(int(self.lib.fp8mi_scaled_mm_workspace_bytes()), dtype=torch.uint8, device=dev)
+                        for _ in range(MAX_STREAMS)]
             self.inner = nbuf * (4 if name == "gemv" else 1)
             if self.sharded:
                 # the shipped N-column-sharded linear (fp8_sharded_linear.py): transposed blocks,
@@ -147,7 +151,8 @@ class Workload:
             self.Bs = [clean_bytes((N, K), dev, gen) for _ in range(nbuf)]
             self.sb = torch.full((1,), 0.01, dtype=torch.float32, device=dev)
             self.Cs = [torch.empty(M, N, dtype=torch.bfloat16, device=dev) for _ in range(2)]
-            self.ws = torch.zeros(int(self.lib.fp8mi_scaled_mm_workspace_bytes()), dtype=torch.uint8, device=dev)
+            self.wss = [torch.zeros(int(self.lib.fp8mi_scaled_mm_workspace_bytes()), dtype=torch.uint8, device=dev)
+                        for _ in range(MAX_STREAMS)]
             self.flops = 2.0 * M * N * K
             self.bytes = float(2 * M * K * 2 + M * K + M * K + N * K + 2 * M * N)
             self.unit_flops = True
@@ -173,8 +178,9 @@ class Workload:
         else:
             raise ValueError(name)
 
-    def launch(self, i, stream):
+    def launch(self, i, stream, chain=0):
         lib = self.lib
+        ws = self.wss[chain] if hasattr(self, "wss") else None
         if self.name in MM_WORKLOADS:
             B = self.Bs[i % len(self.Bs)]
             C = self.Cs[i % 2]
@@ -182,12 +188,12 @@ class Workload:
                 rc = lib.fp8mi_scaled_mm_ws(B.data_ptr(), self.A.data_ptr(), C.data_ptr(), self.sb.data_ptr(),
                                             self.sa.data_ptr(), None, None, self.N, self.M, self.K, self.K, self.K,
                                             self.M, 0, 0, self.code, 0, L.NAN_ZERO, self.kernel, 0,
-                                            self.ws.data_ptr(), self.ws.numel(), stream)
+                                            ws.data_ptr(), ws.numel(), stream)
             else:
                 rc = lib.fp8mi_scaled_mm_ws(self.A.data_ptr(), B.data_ptr(), C.data_ptr(), self.sa.data_ptr(),
                                             self.sb.data_ptr(), None, None, self.M, self.N, self.K, self.K, self.K,
                                             self.N, 0, 0, self.code, 0, L.NAN_ZERO, self.kernel, 0,
-                                            self.ws.data_ptr(), self.ws.numel(), stream)
+                                            ws.data_ptr(), ws.numel(), stream)
         elif self.name == "linear":
             rc = lib.fp8mi_quantize(self.x.data_ptr(), L.BF16, self.xq.data_ptr(), self.scales.data_ptr(), self.x.numel(),
                                     L.ENC_REFERENCE, stream)
@@ -195,7 +201,7 @@ class Workload:
             rc = lib.fp8mi_scaled_mm_ws(self.xq.data_ptr(), self.Bs[i % len(self.Bs)].data_ptr(), self.Cs[i % 2].data_ptr(),
                                         self.scales.data_ptr() + 4, self.sb.data_ptr(), None, None, self.M, self.N, self.K,
                                         self.K, self.K, self.N, 0, 0, L.BF16, 0, L.NAN_ZERO, self.kernel, 0,
-                                        self.ws.data_ptr(), self.ws.numel(), stream)
+                                        ws.data_ptr(), ws.numel(), stream)
         elif self.name == "quantize":
             rc = lib.fp8mi_encode(self.src[0].data_ptr(), L.F32, self.dst[0].data_ptr(), None, self.count,
                                   L.ENC_REFERENCE, stream)
@@ -203,31 +209,45 @@ class Workload:
             rc = lib.fp8mi_dequant(self.src[0].data_ptr(), self.dst[0].data_ptr(), None, self.count, L.F16, stream)
         L.check(rc, f"bench launch {self.name}")
 
-    def step(self):
+    def step(self, streams=None):
         """One step, eagerly on the current stream (also what gets captured)."""
         if self.sharded:
             for i in range(self.inner):
                 self.out = self.linears[i % len(self.linears)](self.A, self.sa)  # (M, N) view of the gathered C^T
+            return
+        if streams:  # independent launches round-robin over side streams (inside a capture: parallel graph branches)
+            cur = torch.cuda.current_stream(self.dev)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            for st in streams:
+                st.wait_event(ev)
+            for i in range(self.inner):
+                self.launch(i, streams[i % len(streams)].cuda_stream, chain=i % len(streams))
+            for st in streams:
+                cur.wait_stream(st)
             return
         s = torch.cuda.current_stream(self.dev).cuda_stream
         for i in range(self.inner):
             self.launch(i, s)
 
 
-def time_steps(w, steps, warmup, use_graph, world):
+def time_steps(w, steps, warmup, use_graph, world, n_streams=1):
     dev = w.dev
     graph = None
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 and not w.sharded else None
+    if w.name in ("quantize", "dequant", "linear"):
+        streams = None  # these reuse one output buffer per launch
     if use_graph and world == 1 and not w.sharded:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            w.step()  # warm every code path before capture
+            w.step(streams)  # warm every code path before capture
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            w.step()
-    run = graph.replay if graph is not None else w.step
+            w.step(streams)
+    run = graph.replay if graph is not None else (lambda: w.step(streams))
     for _ in range(warmup):
         run()
     if world > 1:
@@ -379,9 +399,9 @@ def allgather_only(w, reps=10):
         return {"error": repr(e)}
 
 
-def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info, nbuf=None, sharded=False):
+def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info, nbuf=None, sharded=False, n_streams=1):
     w = Workload(name, dev, world, rank, kernel, nbuf, sharded)
-    dt, graphed = time_steps(w, steps, warmup, True, world)
+    dt, graphed = time_steps(w, steps, warmup, True, world, n_streams)
     launches = steps * w.inner
     if w.unit_flops:
         value, unit = w.flops * world * launches / dt / 1e12, "TFLOP/s"
@@ -389,7 +409,7 @@ def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info, nbuf=
         value, unit = w.bytes * launches / dt / 1e9, "GB/s"
     kd = kernel_durations(w, min(4 * w.inner, 256)) if name != "linear" else None   # the chain is three kernels
     res = {"value": round(value, 3), "unit": unit, "ms_per_step": round(dt / steps * 1e3, 5),
-           "launches_per_step": w.inner, "hip_graph": graphed, "config": w.desc,
+           "launches_per_step": w.inner, "hip_graph": graphed, "streams": n_streams, "config": w.desc,
            "roofline": roofline_of(w, kd, info, load_traffic(name))}
     if w.sharded and dist.is_initialized():
         res["allgather_only"] = allgather_only(w)   # GEMM-only rate is roofline.achieved, this is the collective
@@ -411,6 +431,9 @@ def main():
                     "(1 = weights stay cache-resident; for sensitivity experiments only)")
     ap.add_argument("--data", default="gauss", choices=["gauss", "uniform", "zeros"],
                     help="operand byte distribution (see clean_bytes)")
+    ap.add_argument("--streams", type=int, default=1, choices=range(1, MAX_STREAMS + 1),
+                    help="issue the step's independent launches round-robin over this many streams "
+                         "(parallel branches of the captured graph); 1 = one serial chain (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
@@ -445,7 +468,7 @@ def main():
 
     res = measure(primary, dev, args.steps, args.warmup, world, rank, args.kernel,
                   with_cpu=(world == 1 and rank == 0 and not args.no_cpu_baseline and not args.force_sharded and primary != "linear"),
-                  info=info, nbuf=args.nbuf, sharded=args.force_sharded)
+                  info=info, nbuf=args.nbuf, sharded=args.force_sharded, n_streams=args.streams)
     line = {
         "metric": METRIC, "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
