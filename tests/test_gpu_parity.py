@@ -554,6 +554,32 @@ def test_split_k_full_size_decode_shape(native, cuda, oracle):
     assert _counters_zero(native, cuda)
 
 
+def test_random_shapes_auto_dispatch_fuzz(native, cuda, oracle):
+    """Seeded sweep of 80 random problems through the automatic dispatch (GEMV / skinny / tile kernels with and
+    without split-K / generic), random scale layouts, bias, output type and split_k request: every output element
+    against the oracle.  Catches tile-map, K-slice and edge-masking corner cases the hand-picked shapes miss."""
+    rng = np.random.default_rng(2024)
+    pick = lambda xs: xs[int(rng.integers(len(xs)))]
+    for it in range(80):
+        M = int(pick([1, 2, 3, 7, 16, 31, 33, 48, 64, 65, 100, 128, 129, 200, 256, 300, 511, 640]))
+        N = int(pick([1, 5, 16, 63, 64, 65, 127, 128, 130, 255, 256, 384, 500, 777, 1024]))
+        K = int(pick([16, 32, 112, 128, 144, 256, 272, 512, 1040, 2048, 4096, 4112, 6144])) if rng.random() < 0.9 else int(rng.integers(1, 300))
+        if M * N * K > 6.0e8:   # keep the float64 oracle quick
+            K = 512
+        A, B = clean_bytes(rng, (M, K)), clean_bytes(rng, (N, K))
+        sa = rng.uniform(0.005, 0.02, size=M if rng.random() < 0.5 else 1).astype(np.float32)
+        sb = rng.uniform(0.005, 0.02, size=N if rng.random() < 0.5 else 1).astype(np.float32)
+        bias = rng.normal(size=N).astype(np.float32) if rng.random() < 0.5 else None
+        od = pick([torch.float32, torch.bfloat16, torch.float16])
+        split = int(pick([0, 0, 0, 1, 2, 3, 5, 8]))
+        try:
+            check_mm(oracle, native, cuda, A, B, sa, sb, bias=bias, out_dtype=od, split_k=split, tol=MFMA_TOL)
+        except AssertionError as e:
+            raise AssertionError(f"case {it}: M={M} K={K} N={N} sa={sa.size} sb={sb.size} bias={bias is not None} "
+                                 f"out={od} split_k={split}: {e}") from e
+    assert _counters_zero(native, cuda)
+
+
 def test_graph_capture_of_the_c_abi(native, cuda, oracle):
     """Entry points only enqueue (no sync, no allocation): capturable in a HIP graph."""
     rng = np.random.default_rng(56)
