@@ -410,7 +410,7 @@ def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info, nbuf=
     kd = kernel_durations(w, min(4 * w.inner, 256)) if name != "linear" else None   # the chain is three kernels
     res = {"value": round(value, 3), "unit": unit, "ms_per_step": round(dt / steps * 1e3, 5),
            "launches_per_step": w.inner, "hip_graph": graphed, "streams": n_streams, "config": w.desc,
-           "roofline": roofline_of(w, kd, info, load_traffic(name))}
+           "roofline": roofline_of(w, kd, info, load_traffic(name) if world == 1 and not w.sharded else None)}
     if w.sharded and dist.is_initialized():
         res["allgather_only"] = allgather_only(w)   # GEMM-only rate is roofline.achieved, this is the collective
     if with_cpu:
@@ -447,18 +447,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the product has no CPU path")
-    dev = torch.device("cuda", local)
+    # FP8MI_BENCH_BACKEND=gloo lets several ranks share ONE GPU to rehearse the N > 1 code path (not a measurement)
+    backend = os.environ.get("FP8MI_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     if world > 1 or args.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     if args.gpus != world and rank == 0:
         log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     L.load()
-    info = L.device_info(local)
+    info = L.device_info(dev.index)
 
     primary = args.workload
     if primary == "auto":
