@@ -471,6 +471,19 @@ def main():
     res = measure(primary, dev, args.steps, args.warmup, world, rank, args.kernel,
                   with_cpu=(world == 1 and rank == 0 and not args.no_cpu_baseline and not args.force_sharded and primary != "linear"),
                   info=info, nbuf=args.nbuf, sharded=args.force_sharded, n_streams=args.streams)
+    same_workload_1gpu = None
+    if world > 1:
+        # the N = 1 bench line is C3 (BASELINE.json's single-GPU config); for a like-for-like strong-scaling
+        # reference every rank also times the WHOLE FLUX linear on its own GPU (no sharding, no collective)
+        try:
+            ref = measure("flux", dev, max(3, args.steps // 2), max(1, args.warmup // 2), 1, 0, args.kernel,
+                          with_cpu=False, info=info)
+            same_workload_1gpu = {"value": ref["value"], "unit": ref["unit"], "ms_per_step": ref["ms_per_step"],
+                                  "launches_per_step": ref["launches_per_step"], "hip_graph": ref["hip_graph"],
+                                  "kernel_avg_us": (ref["roofline"] or {}).get("kernel_avg_us")}
+        except Exception as e:
+            same_workload_1gpu = {"error": repr(e)}
+        dist.barrier()
     line = {
         "metric": METRIC, "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
@@ -487,6 +500,8 @@ def main():
     }
     if "allgather_only" in res:
         line["allgather_only"] = res["allgather_only"]
+    if same_workload_1gpu is not None:
+        line["same_workload_on_one_gpu"] = same_workload_1gpu
     if "cpu_baseline" in res:
         line["cpu_baseline"] = res["cpu_baseline"]
 
