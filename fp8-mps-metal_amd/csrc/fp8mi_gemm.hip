@@ -588,16 +588,31 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThr
         __syncthreads();
         const int arrived = *flag;
         if (arrived != nsplit - 1) return;  // workgroup-uniform; nobody waits for anybody
-        for (int s2 = 0; s2 < nsplit; ++s2) {
+        // kBatch slices' loads are in flight together (each is a miss-always read of another XCD's write: one
+        // round trip per slice when issued one after the other - 8 slices cost ~5 us); the additions stay in slice order
+        constexpr int kQuads = C::TN * C::TM;
+        constexpr int kBatch = kQuads <= 4 ? 4 : (kQuads <= 8 ? 3 : (kQuads <= 16 ? 2 : 1));
+        for (int s0 = 0; s0 < nsplit; s0 += kBatch) {
+            f32x4 v[kBatch][C::TN][C::TM];
 #pragma unroll
-            for (int tn = 0; tn < C::TN; ++tn)
+            for (int b = 0; b < kBatch; ++b) {
+                const int s2 = min(s0 + b, nsplit - 1);  // past the end: re-read the last slice (not added)
 #pragma unroll
-                for (int tm = 0; tm < C::TM; ++tm) {
-                    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(
-                        rw, (int)(my_off + (tn * C::TM + tm) * C::kThreads * 16u), (int)((uint32_t)s2 * slice_bytes), kCoherent);
-                    const f32x4 v = __builtin_bit_cast(f32x4, raw);
-                    acc[tn][tm] = s2 == 0 ? v : acc[tn][tm] + v;
+                for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < C::TM; ++tm)
+                        v[b][tn][tm] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            rw, (int)(my_off + (tn * C::TM + tm) * C::kThreads * 16u), (int)((uint32_t)s2 * slice_bytes), kCoherent));
+            }
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) {
+                if (s0 + b < nsplit) {
+#pragma unroll
+                    for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+                        for (int tm = 0; tm < C::TM; ++tm) acc[tn][tm] = (s0 + b == 0) ? v[b][tn][tm] : acc[tn][tm] + v[b][tn][tm];
                 }
+            }
         }
         if (threadIdx.x == 0) __hip_atomic_store(&counters[wg], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // zero for the next launch
         __syncthreads();  // the flag word is part of the ring the staged epilogue reuses
