@@ -180,7 +180,12 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
             // kernel wins from M = 2 (K = 4096, N = 14336: 13.7 vs 25.4 us; M = 32, K = 14336, N = 4096: 17.7 vs
             // 28.4 us) - it needs the workspace
             const bool big = (double)p.N * (double)p.K >= 24.0 * 1048576.0;
-            if (!(p.ws && p.split != 1 && big && fp8mi_gemm_supported(p)))
+            // ... and when N alone yields >= 192 tiles of 128x64 the tile kernel needs no split to fill the chip
+            // (K = 4096, N = 14336: 14-15 us for every M <= 64, skinny 20-36 us: x is re-read by every 16-row workgroup)
+            // (from 128 tiles on while K <= 4096: K = 4096, N = 8192: 14-15 vs 16-19 us; at K = 8192 the 128 busy CUs lose)
+            const int64_t t64 = (p.N + 63) / 64;
+            const bool wide = t64 >= 192 || (t64 >= 128 && p.K <= 4096);
+            if (!(fp8mi_gemm_supported(p) && ((p.ws && p.split != 1 && big) || wide)))
                 return hip_result(fp8mi_launch_skinny(p, s), "skinny");
         }
         if (K > 0 && fp8mi_gemm_supported(p)) return hip_result(fp8mi_launch_gemm(p, FP8MI_KERNEL_AUTO, s), "gemm");
