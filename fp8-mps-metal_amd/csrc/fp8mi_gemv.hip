@@ -169,14 +169,19 @@ int launch(const MMParams &p, hipStream_t s)
 bool fp8mi_gemv_supported(const MMParams &p)
 {
     return p.M == 1 && p.K > 0 && (p.K % 16) == 0 && (p.ldb % 16) == 0 && (((uintptr_t)p.A) & 15u) == 0 &&
-           (((uintptr_t)p.B) & 15u) == 0 && (p.N + 7) / 8 <= 0x7FFFFFFF;
+           (((uintptr_t)p.B) & 15u) == 0 && (p.N + 3) / 4 <= 0x7FFFFFFF;
 }
 
 int fp8mi_launch_gemv(const MMParams &p, hipStream_t s)
 {
     // wave-steps per wave for one pass over K (4 waves x 1 KiB per step)
     const int64_t steps = (p.K + 4095) / 4096;
-    if (steps <= 1) return launch<1, 16>(p, s);
-    if (steps <= 2) return launch<2, 8>(p, s);
+    // rows per workgroup: few rows = many small workgroups, which is what a 5-15 us kernel wants (measured with
+    // tools/time_shape.py; RB = 16 -> 4 at K = 4096: N = 14336 16.3 -> 12.2 us, N = 4096 8.4 -> 5.9 us; K = 8192: 15.8
+    // -> 15.0 us); with four wave-steps per wave (K > 8192) 8 rows are better until the grid gets short of ~450
+    // workgroups (K = 14336, N = 4096: 14.5 vs 15.5 us; K = 12288, N = 3072: 11.8 vs 10.4 us)
+    if (steps <= 1) return launch<1, 4>(p, s);
+    if (steps <= 2) return launch<2, 4>(p, s);
+    if ((p.N + 7) / 8 < 448) return launch<4, 4>(p, s);
     return launch<4, 8>(p, s);  // K > 16384 loops over 16-KiB chunks
 }
