@@ -4,10 +4,10 @@
 // (fp8_mps_native.py:208, fp8_matmul.metal:99-147); batch 4 is one of its three
 // published shapes.  At small M the work is reading W (N x K bytes) once, so the
 // kernel is built like the GEMV, not like the tiled GEMM:
-//   * a workgroup of 8 waves owns 16 x (8 / KW) consecutive rows of W (MFMA n-fragments of 16 rows); KW waves
-//     split one fragment's K round-robin in 128-byte steps and reduce through LDS.  KW = 8 for deep K; for
-//     shallow K fewer waves share a fragment so that every wave still has kU steps to keep in flight
-//     (K = 4096 with KW = 8 left each wave 4 of its 8 load slots: 25 us on a 56 MiB weight matrix);
+//   * a workgroup of KW waves owns 16 consecutive rows of W (one MFMA n-fragment); the waves split K
+//     round-robin in 128-byte steps and reduce through LDS.  KW = 8 for deep K; for shallow K fewer, so that
+//     every wave still has kU steps to keep in flight (K = 4096 with 8 waves left each wave 4 of its 8 load
+//     slots: 25 us on a 56 MiB weight matrix);
 //   * W fragments go HBM -> VGPR directly (non-temporal, no LDS: nothing is
 //     shared between waves), U steps (2U loads of 1 KiB) in flight per wave;
 //     like the GEMV the kernel is latency-, not issue-bound, so depth matters;
@@ -21,17 +21,16 @@
 
 namespace {
 
-constexpr int kWaves = 8;  // K is split 8 ways inside the workgroup
 constexpr int kScaleOne = 0x7F7F7F7F;
 
-template <int TM, int kU /* K-steps per wave in flight */, int KW /* waves sharing one 16-row fragment */>
-__global__ __launch_bounds__(kWaves * 64) void skinny_kernel(MMParams p)
+template <int TM, int kU /* K-steps per wave in flight */, int KW /* waves per workgroup = K shares of its fragment */>
+__global__ __launch_bounds__(KW * 64) void skinny_kernel(MMParams p)
 {
-    __shared__ f32x4 part[kWaves][TM][64];
+    __shared__ f32x4 part[KW][TM][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int rb = wave / KW, kw = wave % KW;  // row block inside the workgroup, K share inside the row block
-    const int64_t n0 = ((int64_t)blockIdx.x * (kWaves / KW) + rb) * 16;
+    const int kw = wave;  // K share
+    const int64_t n0 = (int64_t)blockIdx.x * 16;
     const int64_t K = p.K;
     const int nk = (int)((K + 127) / 128);
     const bool wrow_ok = n0 + r < p.N;
@@ -83,15 +82,15 @@ __global__ __launch_bounds__(kWaves * 64) void skinny_kernel(MMParams p)
 #pragma unroll
     for (int t = 0; t < TM; ++t) part[wave][t][lane] = acc[t];
     __syncthreads();
-    // the KW waves of a row block finish its m-fragments t = kw, kw + KW, ...
+    // the KW waves finish the m-fragments t = kw, kw + KW, ...
     const bool has_bias = p.bias != nullptr, has_sr = p.scale_result != nullptr;
     const float sr = has_sr ? p.scale_result[0] : 1.0f;
     const int esz = p.out_dtype == FP8MI_F32 ? 4 : 2;
     const bool vec_ok = ((p.ldc * esz) % 16) == 0 && (((uintptr_t)p.C) % 16) == 0;
     for (int t = kw; t < TM; t += KW) {
-        f32x4 s = part[rb * KW][t][lane];
+        f32x4 s = part[0][t][lane];
 #pragma unroll
-        for (int w = 1; w < KW; ++w) s += part[rb * KW + w][t][lane];
+        for (int w = 1; w < KW; ++w) s += part[w][t][lane];
         const int64_t m = t * 16 + r;
         if (m >= p.M) continue;
         const float sa = p.sa_row ? p.scale_a[m] : p.scale_a[0];
@@ -119,25 +118,20 @@ __global__ __launch_bounds__(kWaves * 64) void skinny_kernel(MMParams p)
 template <int TM, int kU, int KW>
 int launch_kw(const MMParams &p, hipStream_t s)
 {
-    const int64_t rows_per_wg = 16 * (kWaves / KW);
-    const int64_t grid = (p.N + rows_per_wg - 1) / rows_per_wg;
-    FP8MI_LAUNCH((skinny_kernel<TM, kU, KW>), dim3((unsigned)grid), dim3(kWaves * 64), s, p);
+    const int64_t grid = (p.N + 15) / 16;
+    FP8MI_LAUNCH((skinny_kernel<TM, kU, KW>), dim3((unsigned)grid), dim3(KW * 64), s, p);
     return (int)hipGetLastError();
 }
 
 template <int TM, int kU>
 int launch(const MMParams &p, hipStream_t s)
 {
-    // as few waves per fragment as leaves each of them kU K-steps to keep in flight - but never so few that the
-    // grid (16 x 8 / KW rows per workgroup) drops under ~1.5 workgroups per CU: K = N = 4096 with KW = 4 is 128
-    // workgroups and 1.5 us slower than KW = 8 (256 workgroups), K = 4096, N = 14336 with KW = 4 is 448 and 22 % faster
+    // as few waves per fragment as leaves each of them kU K-steps to keep in flight (K = 4096 with 8 waves left
+    // each wave 4 of its 8 load slots); the grid stays one workgroup per 16 rows of W
     const int64_t nk = (p.K + 127) / 128;
-    const int64_t frags = (p.N + 15) / 16;
-    int kw = nk >= 8 * kU ? 8 : (nk >= 4 * kU ? 4 : (nk >= 2 * kU ? 2 : 1));
-    while (kw < 8 && frags * kw / 8 < 384 && nk > 4) kw *= 2;  // (K <= 512: one wave per fragment wins regardless: 8.6 vs 11.3 us)
-    if (kw == 8) return launch_kw<TM, kU, 8>(p, s);
-    if (kw == 4) return launch_kw<TM, kU, 4>(p, s);
-    if (kw == 2) return launch_kw<TM, kU, 2>(p, s);
+    if (nk >= 8 * kU) return launch_kw<TM, kU, 8>(p, s);
+    if (nk >= 4 * kU) return launch_kw<TM, kU, 4>(p, s);
+    if (nk >= 2 * kU) return launch_kw<TM, kU, 2>(p, s);
     return launch_kw<TM, kU, 1>(p, s);
 }
 
