@@ -434,8 +434,13 @@ __global__ __launch_bounds__(kBlock) void encode_scalar_kernel(const void *__res
 // ---------------------------------------------------------------------------
 // amax: |x| max as float bits through atomicMax on the (non-negative) pattern
 // ---------------------------------------------------------------------------
+// amax runs few, fat workgroups (1024 threads, <= 512 of them): every workgroup ends in one same-address atomic,
+// and those serialise at ~10 ns each - 1536 workgroups finishing together cost ~15 us on a 25 MB tensor
+constexpr int kAmaxBlock = 1024;
+constexpr int kAmaxMaxGrid = 512;
+
 template <int IN>
-__global__ __launch_bounds__(kBlock) void amax_kernel(const void *__restrict__ in, uint32_t *__restrict__ out_bits,
+__global__ __launch_bounds__(kAmaxBlock) void amax_kernel(const void *__restrict__ in, uint32_t *__restrict__ out_bits,
                                                        int64_t count, int vec_ok)
 {
     // like the encode kernel: every wave-instruction reads one contiguous KiB (lane l -> 16 B at 16 l), four of them
@@ -444,9 +449,9 @@ __global__ __launch_bounds__(kBlock) void amax_kernel(const void *__restrict__ i
     constexpr int P = InVec<IN>::kPer;   // elements per 16-byte vector
     constexpr int U = FP8MI_CAST_UNROLL;
     float m = 0.0f;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t stride = (int64_t)gridDim.x * kAmaxBlock;
     const int64_t nv = vec_ok ? count / P : 0;
-    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * kAmaxBlock + threadIdx.x;
     for (; i + (U - 1) * stride < nv; i += U * stride) {
         float f[U][8];
 #pragma unroll
@@ -462,17 +467,17 @@ __global__ __launch_bounds__(kBlock) void amax_kernel(const void *__restrict__ i
 #pragma unroll
         for (int j = 0; j < P; ++j) m = fmaxf(m, fabsf(f[j]));
     }
-    for (int64_t e = nv * P + (int64_t)blockIdx.x * kBlock + threadIdx.x; e < count; e += stride)
+    for (int64_t e = nv * P + (int64_t)blockIdx.x * kAmaxBlock + threadIdx.x; e < count; e += stride)
         m = fmaxf(m, fabsf(InVec<IN>::load1(in, e)));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    __shared__ float wmax[kBlock / 64];
+    __shared__ float wmax[kAmaxBlock / 64];
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
         float b = wmax[0];
 #pragma unroll
-        for (int w = 1; w < kBlock / 64; ++w) b = fmaxf(b, wmax[w]);
+        for (int w = 1; w < kAmaxBlock / 64; ++w) b = fmaxf(b, wmax[w]);
         // Same-address atomics serialise at the memory side (~10 ns each): 2048 workgroups finishing together cost
         // ~20 us on a 25 MB tensor.  The running maximum only grows, so a workgroup whose maximum does not exceed
         // the value it can already see has nothing to add (a stale, smaller value merely costs the atomic).
@@ -547,11 +552,13 @@ int fp8mi_launch_amax(const void *in, int in_dtype, float *out, int64_t count, h
     const int vec = aligned16(in) ? 1 : 0;
     // one 16-byte vector per lane and iteration, FP8MI_CAST_UNROLL of them in flight
     const int per = in_dtype == FP8MI_F32 ? 4 : 8;
-    const int grid = grid_for(vec ? (count / per + FP8MI_CAST_UNROLL - 1) / FP8MI_CAST_UNROLL + 1 : count);
+    const int64_t items = vec ? (count / per + FP8MI_CAST_UNROLL - 1) / FP8MI_CAST_UNROLL + 1 : count;
+    int64_t grid = (items + kAmaxBlock - 1) / kAmaxBlock;
+    grid = grid < 1 ? 1 : (grid > kAmaxMaxGrid ? kAmaxMaxGrid : grid);
     uint32_t *ob = (uint32_t *)out;
-    if (in_dtype == FP8MI_F32) FP8MI_LAUNCH(amax_kernel<FP8MI_F32>, dim3(grid), dim3(kBlock), s, in, ob, count, vec);
-    else if (in_dtype == FP8MI_F16) FP8MI_LAUNCH(amax_kernel<FP8MI_F16>, dim3(grid), dim3(kBlock), s, in, ob, count, vec);
-    else FP8MI_LAUNCH(amax_kernel<FP8MI_BF16>, dim3(grid), dim3(kBlock), s, in, ob, count, vec);
+    if (in_dtype == FP8MI_F32) FP8MI_LAUNCH(amax_kernel<FP8MI_F32>, dim3((unsigned)grid), dim3(kAmaxBlock), s, in, ob, count, vec);
+    else if (in_dtype == FP8MI_F16) FP8MI_LAUNCH(amax_kernel<FP8MI_F16>, dim3((unsigned)grid), dim3(kAmaxBlock), s, in, ob, count, vec);
+    else FP8MI_LAUNCH(amax_kernel<FP8MI_BF16>, dim3((unsigned)grid), dim3(kAmaxBlock), s, in, ob, count, vec);
     return (int)hipGetLastError();
 }
 
