@@ -81,7 +81,8 @@ def check_mm(oracle, native, cuda, A, B, sa, sb, *, kernel=L.KERNEL_AUTO, bias=N
     if out_dtype in (torch.bfloat16, torch.float16):
         # one extra rounding to the 8- / 11-bit significand
         eps = 2.0 ** -8 if out_dtype == torch.bfloat16 else 2.0 ** -11
-        assert np.all(np.abs(g - exact) <= tol * bound + eps * np.abs(exact) + 1e-30)
+        tiny = 2.0 ** -24 if out_dtype == torch.float16 else 0.0   # fp16 subnormal quantum (results below 6e-5)
+        assert np.all(np.abs(g - exact) <= tol * bound + eps * np.abs(exact) + tiny + 1e-30)
     else:
         ratio = np.max(np.abs(g - exact) / (bound + 1e-300))
         assert np.all(np.abs(g - exact) <= tol * bound + 1e-30), f"max err/bound = {ratio:.3e}"
