@@ -13,7 +13,10 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kMaxGrid = 2048;
+// One pass per workgroup up to 2^30 threads (a grid-stride loop only beyond that): with the grid capped at 2048
+// workgroups the 2^30-element casts ran at 4.6-4.7 TB/s, with one-shot workgroups (262,144 of them for the fp32
+// encode) at 5.8 (encode) / 5.3 (dequant) TB/s - the dispatcher keeps the memory pipes fuller than a long loop does.
+constexpr int kMaxGrid = 1 << 22;
 #ifndef FP8MI_CAST_UNROLL
 #define FP8MI_CAST_UNROLL 4  // 16-byte loads in flight per lane in the vector cast kernels
 #endif
