@@ -695,21 +695,21 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     if (variant == FP8MI_KERNEL_AUTO) {
         // Pick the tile by a small cost model fitted to per-dispatch timings on MI355X (tools/sweep_dispatch.py,
         // DESIGN.md 6): time = rounds x (fixed + per-K-step) in us, where a round is one workgroup per CU
-        // (two for the 128x128 tile) and a partly filled last round costs 0.6 + 0.4 x its fill.
+        // (two for the 128x128 tile) and a partly filled last round costs a + b x its fill (fitted per tile).
         //   256x256: 8 + 1.6 nk      128x128: 5.5 + 0.87 nk      128x64: 5 + 0.37 nk        (nk = K / 128)
         // e.g. FLUX 4096x3072x12288: 139 / 158 / 332 -> 256x256; 6144^3: 229 / 227 -> 128x128 (2.25 rounds of
         // 256x256 tiles waste most of the third); C3 512x4096x4096: one round of 128x64 tiles, 16.8.
         const double nk = (double)((p.K + 127) / 128);
-        auto rounds = [](double tiles, double slots) {
+        auto rounds = [](double tiles, double slots, double a, double b) {  // a partly filled round costs a + b x fill
             const double r = tiles / slots, whole = (double)(int64_t)r, part = r - whole;
-            return whole + (part > 0 ? 0.6 + 0.4 * part : 0.0);
+            return whole + (part > 0 ? a + b * part : 0.0);
         };
         const double t256 = (double)(((p.M + 255) / 256) * ((p.N + 255) / 256));
         const double t128 = (double)(((p.M + 127) / 128) * ((p.N + 127) / 128));
         const double t64 = (double)(((p.M + 127) / 128) * ((p.N + 63) / 64));
-        const double us256 = rounds(t256, 256) * (8.0 + 1.6 * nk);
-        const double us128 = rounds(t128, 512) * (5.5 + 0.87 * nk);
-        const double us64 = rounds(t64, 256) * (5.0 + 0.37 * nk);
+        const double us256 = rounds(t256, 256, 0.75, 0.25) * (8.0 + 1.6 * nk);   // (a quarter-filled round of 256x256
+        const double us128 = rounds(t128, 512, 0.55, 0.45) * (5.5 + 0.87 * nk);  //  tiles still costs 0.8 of a full one)
+        const double us64 = rounds(t64, 256, 0.6, 0.4) * (5.0 + 0.37 * nk);
         if (t64 <= 128) {
             // few tiles: one per CU at most, split-K (launch<>) fills the rest of the chip when a workspace came along;
             // with few rows of A the tile is better spent on N
