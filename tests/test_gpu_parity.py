@@ -330,6 +330,7 @@ def test_gemm_tile_kernels_ragged(native, cuda, oracle, kernel, M, K, N):
 
 
 @pytest.mark.parametrize("M,K,N", [(1, 128, 16), (2, 16, 1), (4, 4096, 4096), (4, 1040, 100), (16, 4096, 512), (17, 528, 33),
+                                   (4, 8192, 48), (3, 2048, 40), (40, 8192, 24),   # 8 / 2 / 4 waves per fragment
                                    (33, 2048, 200), (64, 14336, 256), (48, 144, 17)])
 def test_skinny_kernel(native, cuda, oracle, M, K, N):
     """2 <= M <= 64 weight-streaming MFMA kernel (the reference's M <= 16 route,
