@@ -59,6 +59,19 @@ bool fp8mi_next_profile_events(hipEvent_t *start, hipEvent_t *stop)
     return true;
 }
 
+int fp8mi_cu_count()
+{
+    static int cache[64];  // 0 = not asked yet; benign race: every thread writes the same value
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cache[dev];
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cache[dev] = n;
+    }
+    return n;
+}
+
 extern "C" {
 
 int fp8mi_profile_begin(int max_launches)
@@ -127,6 +140,15 @@ int64_t fp8mi_scaled_mm_workspace_bytes(void)
     return (int64_t)FP8MI_WS_COUNTER_BYTES + 2 * 256 * (int64_t)(128 * 64 * 4);
 }
 
+int fp8mi_workspace_reset(void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (!workspace) return fail(FP8MI_E_NULL, "fp8mi_workspace_reset: workspace is NULL");
+    if (workspace_bytes < FP8MI_WS_COUNTER_BYTES) return fail(FP8MI_E_SHAPE, "fp8mi_workspace_reset: workspace smaller than the counter block");
+    hipError_t e = hipMemsetAsync(workspace, 0, FP8MI_WS_COUNTER_BYTES, (hipStream_t)stream);
+    if (e != hipSuccess) return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int fp8mi_scaled_mm_ex(const uint8_t *A, const uint8_t *B_nk, void *C, const float *scale_a, const float *scale_b,
                        const void *bias, const float *scale_result, int64_t M, int64_t N, int64_t K, int64_t lda,
                        int64_t ldb, int64_t ldc, int scale_a_mode, int scale_b_mode, int out_dtype, int bias_dtype,
@@ -149,6 +171,8 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     if (lda < K || ldb < K || ldc < N)
         return fail(FP8MI_E_SHAPE, "fp8mi_scaled_mm: leading dimension too small (lda=%lld ldb=%lld ldc=%lld)",
                     (long long)lda, (long long)ldb, (long long)ldc);
+    const int transposed = (bias_dtype & FP8MI_EPILOGUE_TRANSPOSED) ? 1 : 0;
+    bias_dtype &= ~FP8MI_EPILOGUE_TRANSPOSED;
     if (!dtype_ok(out_dtype) || (bias && !dtype_ok(bias_dtype)))
         return fail(FP8MI_E_ENUM, "fp8mi_scaled_mm: unknown out_dtype / bias_dtype");
     if ((scale_a_mode | 1) != 1 || (scale_b_mode | 1) != 1 || (nan_mode | 1) != 1)
@@ -159,7 +183,7 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     p.scale_a = scale_a; p.scale_b = scale_b; p.bias = bias; p.scale_result = scale_result;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.sa_row = scale_a_mode; p.sb_row = scale_b_mode;
-    p.out_dtype = out_dtype; p.bias_dtype = bias_dtype;
+    p.out_dtype = out_dtype; p.bias_dtype = bias_dtype; p.transposed = transposed;
     p.nan_zero = nan_mode == FP8MI_NAN_ZERO;
     p.debug = 0;
     if (split_k < 0) return fail(FP8MI_E_ENUM, "fp8mi_scaled_mm_ws: split_k must be >= 0");
@@ -183,8 +207,8 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
             // ... and when N alone yields >= 192 tiles of 128x64 the tile kernel needs no split to fill the chip
             // (K = 4096, N = 14336: 14-15 us for every M <= 64, skinny 20-36 us: x is re-read by every 16-row workgroup)
             // (from 128 tiles on while K <= 4096: K = 4096, N = 8192: 14-15 vs 16-19 us; at K = 8192 the 128 busy CUs lose)
-            const int64_t t64 = (p.N + 63) / 64;
-            const bool wide = t64 >= 192 || (t64 >= 128 && p.K <= 4096);
+            const int64_t t64 = (p.N + 63) / 64, cus = fp8mi_cu_count();
+            const bool wide = t64 >= (3 * cus) / 4 || (t64 >= cus / 2 && p.K <= 4096);
             if (!(fp8mi_gemm_supported(p) && ((p.ws && p.split != 1 && big) || wide)))
                 return hip_result(fp8mi_launch_skinny(p, s), "skinny");
         }
@@ -200,14 +224,17 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     case FP8MI_KERNEL_GEMM_128x64:
     case FP8MI_KERNEL_GEMM_256:
     case FP8MI_KERNEL_GEMM_64x128:
-    case 7: case 8: case 9: case 10: case 11: case 12: case 13:  // schedule variants for A/B timing
-        if (!fp8mi_gemm_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "MFMA gemm kernel needs K %% 16 == 0 and 16-byte aligned rows");
+        if (K <= 0 || !fp8mi_gemm_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "MFMA gemm kernel needs K > 0, K %% 16 == 0 and 16-byte aligned rows");
         return hip_result(fp8mi_launch_gemm(p, kernel, s), "gemm");
     case FP8MI_KERNEL_GENERIC:
         return hip_result(fp8mi_launch_generic(p, s), "generic");
     default:
-#ifdef FP8MI_ABLATE
-        if (kernel >= 100 && kernel < 120 && fp8mi_gemm_supported(p)) return hip_result(fp8mi_launch_gemm(p, kernel, s), "gemm-ablate");
+#ifdef FP8MI_DIAG  // diagnostic library only: schedule variants of the ring kernel (7..13, 30..37), the producer / consumer kernel
+                   // (15..24) and its timing-only ablations (201..207)
+        if (K > 0 && fp8mi_gemm_supported(p)) {
+            if ((kernel >= 7 && kernel <= 13) || (kernel >= 30 && kernel <= 37)) return hip_result(fp8mi_launch_gemm(p, kernel, s), "gemm-variant");
+            if ((kernel >= 15 && kernel <= 24) || (kernel >= 200 && kernel < 220)) return hip_result(fp8mi_launch_gemm_pc(p, kernel, s), "gemm-pc");
+        }
 #endif
         return fail(FP8MI_E_ENUM, "fp8mi_scaled_mm_ex: unknown kernel id %d", kernel);
     }

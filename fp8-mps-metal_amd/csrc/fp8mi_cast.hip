@@ -515,16 +515,13 @@ int fp8mi_launch_dequant(const uint8_t *in, void *out, const float *scale, int64
     if (count == 0) return 0;
     const bool vec = aligned16(in) && aligned16(out);
     const int grid = grid_for(vec ? (count >> 6) : count);  // vector kernel: 4 x 16 bytes per lane per pass
-#define FP8MI_DQ(OUT)                                                                              \
-    do {                                                                                           \
-        if (vec) FP8MI_LAUNCH(dequant_kernel<OUT>, dim3(grid), dim3(kBlock), s, in, out, scale, count); \
-        else FP8MI_LAUNCH(dequant_scalar_kernel<OUT>, dim3(grid), dim3(kBlock), s, in, out, scale, count); \
-    } while (0)
-    if (out_dtype == FP8MI_F16) FP8MI_DQ(FP8MI_F16);
-    else if (out_dtype == FP8MI_F32) FP8MI_DQ(FP8MI_F32);
-    else FP8MI_DQ(FP8MI_BF16);
+#define FP8MI_DQ(OUT)                                                                                          \
+    (vec ? fp8mi_launch(dequant_kernel<OUT>, dim3(grid), dim3(kBlock), s, in, out, scale, count)               \
+         : fp8mi_launch(dequant_scalar_kernel<OUT>, dim3(grid), dim3(kBlock), s, in, out, scale, count))
+    if (out_dtype == FP8MI_F16) return FP8MI_DQ(FP8MI_F16);
+    if (out_dtype == FP8MI_F32) return FP8MI_DQ(FP8MI_F32);
+    return FP8MI_DQ(FP8MI_BF16);
 #undef FP8MI_DQ
-    return (int)hipGetLastError();
 }
 
 template <int IN, bool FROM_AMAX = false>
@@ -536,13 +533,11 @@ static int launch_encode_in(const void *in, uint8_t *out, const float *prescale,
     // one-vector workgroups instead reach only 5.1 TB/s)
     const int grid = grid_for(vec ? (count >> 4) + 1 : count);
     if (mode == FP8MI_ENC_REFERENCE) {
-        if (vec) FP8MI_LAUNCH((encode_kernel<IN, FP8MI_ENC_REFERENCE, FROM_AMAX>), dim3(grid), dim3(kBlock), s, in, out, prescale, count);
-        else FP8MI_LAUNCH((encode_scalar_kernel<IN, FP8MI_ENC_REFERENCE, FROM_AMAX>), dim3(grid), dim3(kBlock), s, in, out, prescale, count);
-    } else {
-        if (vec) FP8MI_LAUNCH((encode_kernel<IN, FP8MI_ENC_RNE, FROM_AMAX>), dim3(grid), dim3(kBlock), s, in, out, prescale, count);
-        else FP8MI_LAUNCH((encode_scalar_kernel<IN, FP8MI_ENC_RNE, FROM_AMAX>), dim3(grid), dim3(kBlock), s, in, out, prescale, count);
+        if (vec) return fp8mi_launch(encode_kernel<IN, FP8MI_ENC_REFERENCE, FROM_AMAX>, dim3(grid), dim3(kBlock), s, in, out, prescale, count);
+        return fp8mi_launch(encode_scalar_kernel<IN, FP8MI_ENC_REFERENCE, FROM_AMAX>, dim3(grid), dim3(kBlock), s, in, out, prescale, count);
     }
-    return (int)hipGetLastError();
+    if (vec) return fp8mi_launch(encode_kernel<IN, FP8MI_ENC_RNE, FROM_AMAX>, dim3(grid), dim3(kBlock), s, in, out, prescale, count);
+    return fp8mi_launch(encode_scalar_kernel<IN, FP8MI_ENC_RNE, FROM_AMAX>, dim3(grid), dim3(kBlock), s, in, out, prescale, count);
 }
 
 int fp8mi_launch_encode(const void *in, int in_dtype, uint8_t *out, const float *prescale, int64_t count, int mode,
@@ -566,10 +561,9 @@ int fp8mi_launch_amax(const void *in, int in_dtype, float *out, int64_t count, h
     int64_t grid = (items + kAmaxBlock - 1) / kAmaxBlock;
     grid = grid < 1 ? 1 : (grid > kAmaxMaxGrid ? kAmaxMaxGrid : grid);
     uint32_t *ob = (uint32_t *)out;
-    if (in_dtype == FP8MI_F32) FP8MI_LAUNCH(amax_kernel<FP8MI_F32>, dim3((unsigned)grid), dim3(kAmaxBlock), s, in, ob, count, vec);
-    else if (in_dtype == FP8MI_F16) FP8MI_LAUNCH(amax_kernel<FP8MI_F16>, dim3((unsigned)grid), dim3(kAmaxBlock), s, in, ob, count, vec);
-    else FP8MI_LAUNCH(amax_kernel<FP8MI_BF16>, dim3((unsigned)grid), dim3(kAmaxBlock), s, in, ob, count, vec);
-    return (int)hipGetLastError();
+    if (in_dtype == FP8MI_F32) return fp8mi_launch(amax_kernel<FP8MI_F32>, dim3((unsigned)grid), dim3(kAmaxBlock), s, in, ob, count, vec);
+    if (in_dtype == FP8MI_F16) return fp8mi_launch(amax_kernel<FP8MI_F16>, dim3((unsigned)grid), dim3(kAmaxBlock), s, in, ob, count, vec);
+    return fp8mi_launch(amax_kernel<FP8MI_BF16>, dim3((unsigned)grid), dim3(kAmaxBlock), s, in, ob, count, vec);
 }
 
 int fp8mi_launch_quantize(const void *in, int in_dtype, uint8_t *out, float *scales, int64_t count, int mode,

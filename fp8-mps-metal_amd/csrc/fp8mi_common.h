@@ -33,6 +33,8 @@ struct MMParams {
     int64_t lda, ldb, ldc;
     int sa_row, sb_row;    // 0 per-tensor, 1 per-row
     int out_dtype, bias_dtype;
+    int transposed;        // 1: the caller computes C^T = B . A^T (sharded linear): bias runs along M (bias[m]) and the epilogue
+                           //    multiplies by scale_b first, then scale_a - the bits of the untransposed fused epilogue
     int nan_zero;          // 1: NaN bytes decode to 0 (reference), 0: propagate
     int debug;             // diagnostic builds only (FP8MI_STAMP): ablation bits, else 0
     int split;             // GEMM tile kernels: number of K ranges per tile (1 = no split-K)
@@ -41,6 +43,24 @@ struct MMParams {
 };
 
 constexpr int kWsCounterBytes = 4096;  // 1024 tile counters, zero between launches
+
+// Kernel arguments arrive through the kernarg segment, which the runtime may keep in HOST memory (a scalar load from it
+// is a PCIe round trip, ~1.5 us; HIP_FORCE_DEV_KERNARG=1 moves it to HBM, ~0.5 us).  Left alone, hipcc loads the fields
+// lazily - the GEMM had four dependent load-and-wait groups ahead of its first DMA and another in the epilogue, 4.6 us
+// from kernel entry to the K loop (in-kernel stamps, profiles/r02_stamps.txt).  pin_params() makes every field opaque at
+// kernel entry: all scalar loads issue as ONE clause with one wait, and the values then live in SGPRs (the compiler
+// cannot re-derive them from the kernarg pointer later).
+#define FP8MI_PIN_S(x) asm volatile("" : "+s"(x))
+FP8MI_DEVICE MMParams pin_params(const MMParams &p)
+{
+    MMParams q = p;
+    FP8MI_PIN_S(q.A); FP8MI_PIN_S(q.B); FP8MI_PIN_S(q.C); FP8MI_PIN_S(q.scale_a); FP8MI_PIN_S(q.scale_b);
+    FP8MI_PIN_S(q.bias); FP8MI_PIN_S(q.scale_result);
+    FP8MI_PIN_S(q.M); FP8MI_PIN_S(q.N); FP8MI_PIN_S(q.K); FP8MI_PIN_S(q.lda); FP8MI_PIN_S(q.ldb); FP8MI_PIN_S(q.ldc);
+    FP8MI_PIN_S(q.sa_row); FP8MI_PIN_S(q.sb_row); FP8MI_PIN_S(q.out_dtype); FP8MI_PIN_S(q.bias_dtype);
+    FP8MI_PIN_S(q.transposed); FP8MI_PIN_S(q.nan_zero); FP8MI_PIN_S(q.split); FP8MI_PIN_S(q.ws); FP8MI_PIN_S(q.ws_bytes);
+    return q;
+}
 
 // SWAR scrub: zero every byte of w whose low 7 bits are all ones (the two
 // e4m3fn NaN patterns 0x7F / 0xFF), i.e. the reference's decode rule
@@ -93,9 +113,9 @@ FP8MI_DEVICE void store_from_float(void *p, int64_t i, float v, int dtype)
 // The reference epilogue, in its order (fp8_matmul.metal:144-146 then
 // fp8_mps_patch.py:94-104): (sum * sa) * sb, + bias, * scale_result, cast.
 FP8MI_DEVICE float epilogue_value(float sum, float sa, float sb, bool has_bias, float bias,
-                                  bool has_sr, float sr)
+                                  bool has_sr, float sr, bool transposed = false)
 {
-    float r = (sum * sa) * sb;
+    float r = transposed ? (sum * sb) * sa : (sum * sa) * sb;
     if (has_bias) r = r + bias;
     if (has_sr) r = r * sr;
     return r;
@@ -109,20 +129,24 @@ FP8MI_DEVICE float wave_sum(float v)
     return v;
 }
 
-// Per-dispatch timing hook (fp8mi_profile_begin / _end in the C ABI): while a
-// profile is open on the calling thread every kernel launch carries its own
-// start/stop event pair, filled from the dispatch packet's timestamps - the
-// same clock rocprofv3 --kernel-trace reads.  Outside a profile this is a
-// plain launch.
+// Per-dispatch timing hook (fp8mi_profile_begin / _end in the C ABI): while a profile is open on the calling thread
+// every kernel launch carries its own start/stop event pair, filled from the dispatch packet's timestamps - the same
+// clock rocprofv3 --kernel-trace reads.  Outside a profile this is a plain launch.
 bool fp8mi_next_profile_events(hipEvent_t *start, hipEvent_t *stop);
-#define FP8MI_LAUNCH(kernel, grid, block, stream, ...)                                         \
-    do {                                                                                       \
-        hipEvent_t e0_, e1_;                                                                   \
-        if (fp8mi_next_profile_events(&e0_, &e1_))                                             \
-            hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, e0_, e1_, 0, __VA_ARGS__);   \
-        else                                                                                   \
-            hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                   \
-    } while (0)
+
+// Launch with the status of THIS launch (hipGetLastError() would report - and clear - any earlier error on the thread).
+template <typename... KArgs>
+int fp8mi_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream_t s, KArgs... args)
+{
+    void *argv[] = {(void *)&args...};
+    hipEvent_t e0, e1;
+    if (fp8mi_next_profile_events(&e0, &e1))
+        return (int)hipExtLaunchKernel((const void *)kernel, grid, block, argv, 0, s, e0, e1, 0);
+    return (int)hipLaunchKernel((const void *)kernel, grid, block, argv, 0, s);
+}
+
+// compute units of the current device (cached per device; the dispatch heuristics scale with it)
+int fp8mi_cu_count();
 
 // launchers implemented in the .hip files (host side, internal linkage by name)
 int fp8mi_launch_gemv(const MMParams &p, hipStream_t s);
@@ -131,4 +155,5 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s);
 bool fp8mi_gemm_supported(const MMParams &p);
 int fp8mi_launch_generic(const MMParams &p, hipStream_t s);
 int fp8mi_launch_skinny(const MMParams &p, hipStream_t s);
+int fp8mi_launch_gemm_pc(const MMParams &p, int variant, hipStream_t s);  // diagnostic library only
 bool fp8mi_skinny_supported(const MMParams &p);

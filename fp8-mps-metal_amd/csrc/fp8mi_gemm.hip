@@ -52,28 +52,22 @@
 // every fragment.  Clean inputs (everything the reference's encoder can emit)
 // never pay for it.
 
-#include "fp8mi_common.h"
+#include "fp8mi_gemm_epi.h"
 
 namespace {
-
-constexpr int BK = 128;  // bytes (= k elements) per K-step
-constexpr uint32_t kOOB = 0x80000000u;
-constexpr int kScaleOne = 0x7F7F7F7F;  // E8M0 127 = 2^0 in every byte
-static_assert(kWsCounterBytes == FP8MI_WS_COUNTER_BYTES, "include/fp8mi.h and the kernels agree on the counter block");
-
-typedef __attribute__((address_space(3))) void lds_void;
 
 template <int BM, int BN, int WM, int WN, int NSTAGE_, int MODE_ = 0, int ABL_ = 0, int KS_ = 1, int LD_ = 0>
 struct Cfg {
     static constexpr int KS = KS_;      // K-steps (of 128 bytes) per ring stage: KS = 2 halves the barriers per byte
-    static constexpr int ABL = ABL_;    // timing-only ablation bits (diagnostic library only; 0 in the product)
-    static constexpr int MODE = MODE_;  // reserved (0 = the ring loop below; other schedules were measured and dropped)
+    static constexpr int ABL = ABL_;    // unused (the ablation study moved to the producer/consumer kernel's diagnostic build)
+    static constexpr int MODE = MODE_;  // 0: stage DMA issued first, then fragment reads + MFMAs; 1: fragment reads first (see run_tile)
     static constexpr int NSTAGE = NSTAGE_;
     static constexpr int PF = NSTAGE_ - 1;  // K-steps of loads in flight
     static constexpr int kWavesM = BM / WM;
     static constexpr int kWavesN = BN / WN;
     static constexpr int kWaves = kWavesM * kWavesN;
     static constexpr int kThreads = kWaves * 64;
+    static constexpr int kCThreads = kThreads;  // every wave holds accumulators
     static constexpr int TM = WM / 16;
     static constexpr int TN = WN / 16;
     static constexpr int kGroupsA = BM / 8;  // 8-row staging groups
@@ -92,8 +86,8 @@ struct Cfg {
                   "each loading wave stages whole groups of both operands; the shared swizzle needs an even count");
     static constexpr int kRingBytes = NSTAGE_ * kStageBytes;
     static_assert(NSTAGE_ >= 2 && NSTAGE_ <= 6 && (NSTAGE_ - 1) * kGroupsPerWave <= 63, "vmcnt is a 6-bit counter");
-    static_assert(kRingBytes <= 160 * 1024, "LDS is 160 KiB per CU");
-    static_assert(MODE_ == 0, "only the ring loop is built");
+    static_assert(kRingBytes + 16 <= 160 * 1024, "LDS is 160 KiB per CU");
+    static_assert(MODE_ >= 0 && MODE_ <= 2 && (MODE_ != 2 || KS_ == 1), "three orders of the loop body are built (the staggered one for KS = 1)");
 };
 
 // one K-step's fragments: LDS -> registers
@@ -245,6 +239,8 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
     const int nk_all = (int)((K + BK * C::KS - 1) / (BK * C::KS));
     const bool ktail = (K % (BK * C::KS)) != 0;  // then the tile's last stage is staged with per-lane K masking
     if (nk == 0) return;
+    unsigned long long p0_ = 0, p1_ = 0, p2_ = 0; (void)p0_; (void)p1_; (void)p2_;
+    STAMP(p0_);
 
     // The K loop is walked circularly from `rot` (a per-m-tile offset): the tiles
     // that share a B panel run at the same time on one XCD, and if they all
@@ -259,6 +255,7 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
     for (int s = 0; s < C::PF; ++s)
         if (s < nk) issue_any<C>(pl, ra, rb, smem + s * C::kStageBytes, wave, next_ks(), nk_all, ktail, K);
 
+    STAMP(p1_);
     int slot = 0;             // ring slot of step t
     int fill = C::PF % C::NSTAGE;  // ring slot the next issue goes to (= slot of step t-1)
     unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
@@ -270,30 +267,26 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
         STAMP(s1);
         __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave is done reading slot of step t-1
         STAMP(s2);
-        if (!(C::ABL & 1)) {
+        if constexpr (C::MODE == 1) {
+            // reads first: this K-step's fragment reads are issued BEFORE the stage DMA, so that they land while the
+            // loading waves sit in the DMA issue (a `buffer_load ... lds` holds its wave ~64 cycles: 1,085 cycles per
+            // K-step on the 256x256 tile, in-kernel stamps) and the MFMAs start the moment the issue is through
+            i32x8 xf[C::TM], wf[C::TN];
+            const uint8_t *st = smem + slot * C::kStageBytes;
+            load_frags<C, SCRUB>(st, st + C::kGroupsA * 1024, wm0, wn0, off1, off2, xf, wf);
+            __builtin_amdgcn_sched_barrier(0);
             if (t + C::PF < nk) issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, next_ks(), nk_all, ktail, K);
-        }
-        STAMP(s3);
-        if constexpr (C::ABL == 0) {
+            STAMP(s3);
+            mfma_all<C>(xf, wf, acc);
+#pragma unroll
+            for (int q = 1; q < C::KS; ++q)
+                compute_step<C, SCRUB>(st + q * C::kStepBytes, wm0, wn0, off1, off2, acc);
+        } else {
+            if (t + C::PF < nk) issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, next_ks(), nk_all, ktail, K);
+            STAMP(s3);
 #pragma unroll
             for (int q = 0; q < C::KS; ++q)
                 compute_step<C, SCRUB>(smem + slot * C::kStageBytes + q * C::kStepBytes, wm0, wn0, off1, off2, acc);
-        } else {  // timing-only ablations (diagnostic library): 1 no LDS-DMA, 2 no ds_read, 4 no MFMA
-            i32x8 xf_[C::TM], wf_[C::TN];
-            if constexpr (!(C::ABL & 2)) load_frags<C, SCRUB>(smem + slot * C::kStageBytes, smem + slot * C::kStageBytes + C::kGroupsA * 1024, wm0, wn0, off1, off2, xf_, wf_);
-            else {
-#pragma unroll
-                for (int i = 0; i < C::TM; ++i) xf_[i] = i32x8{t, t, t, t, t, t, t, t};
-#pragma unroll
-                for (int i = 0; i < C::TN; ++i) wf_[i] = i32x8{t, 1, t, 1, t, 1, t, 1};
-            }
-            if constexpr (!(C::ABL & 4)) mfma_all<C>(xf_, wf_, acc);
-            else {
-#pragma unroll
-                for (int i = 0; i < C::TM; ++i) asm volatile("" ::"v"(xf_[i]));
-#pragma unroll
-                for (int i = 0; i < C::TN; ++i) asm volatile("" ::"v"(wf_[i]));
-            }
         }
         STAMP(s4);
         c_wait += s1 - s0; c_bar += s2 - s1; c_issue += s3 - s2; c_comp += s4 - s3;
@@ -312,150 +305,77 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
         o[0] = c_wait; o[1] = c_bar; o[2] = c_issue; o[3] = c_comp; o[4] = nk;
     }
 #endif
-    // all loads were waited for in the last iteration (newer_stages == 0); make the ring reusable
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
-
-// Fused epilogue, in the reference's order (fp8_matmul.metal:144-146, then
-// fp8_mps_patch.py:94-104): (acc * sa) * sb, + bias, * scale_result, cast.
-// Lane (fr = lane & 15, fg = lane >> 4) holds, per 16x16 fragment (tn, tm), the
-// 4 consecutive columns n = tn*16 + 4 fg + j of row m = tm*16 + fr: one 16-byte
-// (fp32) or 8-byte (bf16 / f16) store.  Column scales and bias are loaded once
-// per lane, row scales once per fragment row; everything else is 32-bit math.
-template <typename C, int OUT>
-FP8MI_DEVICE void epilogue(const MMParams &p, const f32x4 (&acc)[C::TN][C::TM], int64_t m0, int64_t n0, int wm0,
-                           int wn0, int fr, int fg, int rows_m, int cols_n, int vec_store)
-{
-    const bool has_bias = p.bias != nullptr;
-    const float sr = p.scale_result ? p.scale_result[0] : 1.0f;
-    const bool has_sr = p.scale_result != nullptr;
-    float sbv[C::TN][4], bv[C::TN][4];
-    const float sb0 = p.scale_b[0];
-#pragma unroll
-    for (int tn = 0; tn < C::TN; ++tn)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nl = min(wn0 + tn * 16 + fg * 4 + j, cols_n - 1);  // clamped: the value is unused past the edge
-            sbv[tn][j] = p.sb_row ? p.scale_b[n0 + nl] : sb0;
-            bv[tn][j] = has_bias ? load_as_float(p.bias, n0 + nl, p.bias_dtype) : 0.0f;
-        }
-    const float sa0 = p.scale_a[0];
-    constexpr int kEsz = OUT == FP8MI_F32 ? 4 : 2;
-#pragma unroll
-    for (int tm = 0; tm < C::TM; ++tm) {
-        const int ml = wm0 + tm * 16 + fr;
-        if (ml >= rows_m) continue;
-        const float sa = p.sa_row ? p.scale_a[m0 + ml] : sa0;
-        uint8_t *row = (uint8_t *)p.C + ((m0 + ml) * p.ldc + n0) * kEsz;
-#pragma unroll
-        for (int tn = 0; tn < C::TN; ++tn) {
-            const int nl = wn0 + tn * 16 + fg * 4;
-            if (nl >= cols_n) continue;
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float r = (acc[tn][tm][j] * sa) * sbv[tn][j];
-                if (has_bias) r = r + bv[tn][j];
-                if (has_sr) r = r * sr;
-                v[j] = r;
-            }
-            uint8_t *dst = row + nl * kEsz;
-            if (vec_store && nl + 3 < cols_n) {
-                if (OUT == FP8MI_F32) {
-                    *(f32x4 *)dst = f32x4{v[0], v[1], v[2], v[3]};
-                } else if (OUT == FP8MI_BF16) {
-                    __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1], h2 = (__bf16)v[2], h3 = (__bf16)v[3];
-                    *(u32x2 *)dst = u32x2{(uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16),
-                                          (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16)};
-                } else {
-                    _Float16 h0 = (_Float16)v[0], h1 = (_Float16)v[1], h2 = (_Float16)v[2], h3 = (_Float16)v[3];
-                    *(u32x2 *)dst = u32x2{(uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16),
-                                          (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16)};
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (nl + j < cols_n) {
-                        if (OUT == FP8MI_F32) ((float *)dst)[j] = v[j];
-                        else if (OUT == FP8MI_BF16) ((__bf16 *)dst)[j] = (__bf16)v[j];
-                        else ((_Float16 *)dst)[j] = (_Float16)v[j];
-                    }
-                }
-            }
-        }
+    // all loads were waited for in the last iteration (newer_stages == 0); the caller's barrier makes the ring reusable
+#ifdef FP8MI_STAMP
+    STAMP(p2_);
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && wave == 0) {
+        unsigned long long *o = g_stamp + blockIdx.x * 32 + 26;
+        o[0] = p0_; o[1] = p1_; o[2] = p2_;
     }
+#endif
 }
 
-// Epilogue for FULL tiles: same arithmetic, but each wave transposes its output
-// through a private corner of the (now idle) LDS ring so that every global store
-// instruction writes whole 128-byte lines (8 rows x 128 B for 16-bit outputs,
-// 4 rows x 256 B for fp32) instead of 16 scattered 32- / 64-byte pieces - the
-// direct form was store-issue bound (22k of 112k cycles per 256x256 bf16 tile).
-template <typename C, int OUT>
-FP8MI_DEVICE void epilogue_staged(const MMParams &p, const f32x4 (&acc)[C::TN][C::TM], uint8_t *smem, int64_t m0,
-                                  int64_t n0, int wave, int wm0, int wn0, int lane)
+// STAGGERED wave groups (MODE 2).  Left alone all 8 waves run in lockstep: first everybody reads fragments (the LDS is
+// the bottleneck and the matrix pipes idle: 192 KiB per K-step of a 256x256 tile = 768 cycles at 256 B/clk), then everybody
+// multiplies (the LDS idles).  Here waves kWaves/2.. ("late") run half a step behind their SIMD partners: they multiply
+// K-step t - 1, whose fragments they kept in registers across the barrier, while waves 0..kWaves/2-1 read K-step t; then
+// they read K-step t while the partners multiply it.  Same instructions per wave, same registers, same number of
+// barriers, bit-identical results; two separate loops so that each keeps one clean register assignment.
+template <typename C, bool SCRUB>
+FP8MI_DEVICE void run_tile_staggered(const MMParams &p, uint8_t *smem, const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra,
+                                     __amdgpu_buffer_rsrc_t rb, int wave, int wm0, int wn0, uint32_t off1, uint32_t off2,
+                                     int ks0, int nk, int rot, f32x4 (&acc)[C::TN][C::TM])
 {
-    constexpr int kEsz = OUT == FP8MI_F32 ? 4 : 2;
-    constexpr int WNc = C::TN * 16;              // columns of the wave tile
-    constexpr int kRowBytes = WNc * kEsz;        // 64 .. 256
-    constexpr int kStride = kRowBytes + 16;      // padded: spreads the 16 rows over the banks
-    constexpr int kCPR = kRowBytes / 16;         // 16-byte chunks per row
-    constexpr int kRPI = 64 / kCPR;              // rows written per store instruction
-    constexpr int kNI = 16 / kRPI;               // store instructions per 16-row fragment
-    static_assert(C::kWaves * 16 * kStride <= C::kRingBytes, "staging fits in the ring");
-    uint8_t *buf = smem + wave * (16 * kStride);
-    const int fr = lane & 15, fg = lane >> 4;
-
-    const bool has_bias = p.bias != nullptr, has_sr = p.scale_result != nullptr;
-    const float sr = has_sr ? p.scale_result[0] : 1.0f;
-    float sbv[C::TN][4], bv[C::TN][4];
-    const float sb0 = p.scale_b[0], sa0 = p.scale_a[0];
+    static_assert(C::KS == 1, "one K-step per ring stage");
 #pragma unroll
     for (int tn = 0; tn < C::TN; ++tn)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t n = n0 + wn0 + tn * 16 + fg * 4 + j;
-            sbv[tn][j] = p.sb_row ? p.scale_b[n] : sb0;
-            bv[tn][j] = has_bias ? load_as_float(p.bias, n, p.bias_dtype) : 0.0f;
+        for (int tm = 0; tm < C::TM; ++tm) acc[tn][tm] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int64_t K = p.K;
+    const int nk_all = (int)((K + BK - 1) / BK);
+    const bool ktail = (K % BK) != 0;
+    if (nk == 0) return;
+    int ks = rot;
+    auto next_ks = [&]() { const int r = ks; ks = (ks + 1 == nk) ? 0 : ks + 1; return ks0 + r; };
+#pragma unroll
+    for (int s = 0; s < C::PF; ++s)
+        if (s < nk) issue_any<C>(pl, ra, rb, smem + s * C::kStageBytes, wave, next_ks(), nk_all, ktail, K);
+    int slot = 0, fill = C::PF % C::NSTAGE;
+    auto advance = [&]() {
+        slot = (slot + 1 == C::NSTAGE) ? 0 : slot + 1;
+        fill = (fill + 1 == C::NSTAGE) ? 0 : fill + 1;
+    };
+    i32x8 xf[C::TM], wf[C::TN];
+    if (wave < C::kWaves / 2) {  // early group: read, (load,) multiply
+        for (int t = 0; t < nk; ++t) {
+            wait_stage<C>(min(C::PF - 1, nk - 1 - t));
+            __builtin_amdgcn_s_barrier();
+            const uint8_t *st = smem + slot * C::kStageBytes;
+            load_frags<C, SCRUB>(st, st + C::kGroupsA * 1024, wm0, wn0, off1, off2, xf, wf);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + C::PF < nk) issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, next_ks(), nk_all, ktail, K);
+            mfma_all<C>(xf, wf, acc);
+            advance();
         }
-    const int rrow = lane / kCPR, rchunk = lane % kCPR;  // this lane's (row, 16-byte chunk) when reading back
+    } else {                     // late group: multiply the previous K-step, (load,) read this one
+        for (int t = 0; t < nk; ++t) {
+            wait_stage<C>(min(C::PF - 1, nk - 1 - t));
+            __builtin_amdgcn_s_barrier();
+            if (t > 0) {
+                mfma_all<C>(xf, wf, acc);
 #pragma unroll
-    for (int tm = 0; tm < C::TM; ++tm) {
-        const float sa = p.sa_row ? p.scale_a[m0 + wm0 + tm * 16 + fr] : sa0;
+                for (int tn = 0; tn < C::TN; ++tn)
 #pragma unroll
-        for (int tn = 0; tn < C::TN; ++tn) {
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float r = (acc[tn][tm][j] * sa) * sbv[tn][j];
-                if (has_bias) r = r + bv[tn][j];
-                if (has_sr) r = r * sr;
-                v[j] = r;
+                    for (int tm = 0; tm < C::TM; ++tm) asm volatile("" : "+v"(acc[tn][tm]));  // the MFMAs stay above the reads
             }
-            uint8_t *d = buf + fr * kStride + (tn * 16 + fg * 4) * kEsz;
-            if (OUT == FP8MI_F32) {
-                *(f32x4 *)d = f32x4{v[0], v[1], v[2], v[3]};
-            } else if (OUT == FP8MI_BF16) {
-                __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1], h2 = (__bf16)v[2], h3 = (__bf16)v[3];
-                *(u32x2 *)d = u32x2{(uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16),
-                                    (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16)};
-            } else {
-                _Float16 h0 = (_Float16)v[0], h1 = (_Float16)v[1], h2 = (_Float16)v[2], h3 = (_Float16)v[3];
-                *(u32x2 *)d = u32x2{(uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16),
-                                    (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16)};
-            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + C::PF < nk) issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, next_ks(), nk_all, ktail, K);
+            const uint8_t *st = smem + slot * C::kStageBytes;
+            load_frags<C, SCRUB>(st, st + C::kGroupsA * 1024, wm0, wn0, off1, off2, xf, wf);
+            advance();
         }
-        // same wave wrote and reads: DS operations of one wave execute in order
-        uint8_t *grow = (uint8_t *)p.C + ((m0 + wm0 + tm * 16) * p.ldc + n0 + wn0) * kEsz;
-#pragma unroll
-        for (int i = 0; i < kNI; ++i) {
-            const int r = i * kRPI + rrow;
-            u32x4 q = *(const u32x4 *)(buf + r * kStride + rchunk * 16);
-            // streaming store: C is written once and not re-read by this kernel, so it should not displace the
-            // A / B panels in L2 (measured: C3 -3 %, 128x128 shard -5 %, FLUX -1 %)
-            __builtin_nontemporal_store(q, (u32x4 *)(grow + (int64_t)r * p.ldc * kEsz + rchunk * 16));
-        }
+        mfma_all<C>(xf, wf, acc);  // the last K-step
     }
 }
 
@@ -464,37 +384,28 @@ FP8MI_DEVICE void run_tile_any(const MMParams &p, uint8_t *smem, const StagePlan
                                __amdgpu_buffer_rsrc_t rb, int wave, int wm0, int wn0, uint32_t off1, uint32_t off2,
                                int ks0, int nk, int rot, f32x4 (&acc)[C::TN][C::TM])
 {
-    run_tile<C, SCRUB>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, ks0, nk, rot, acc);
+    if constexpr (C::MODE == 2) run_tile_staggered<C, SCRUB>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, ks0, nk, rot, acc);
+    else run_tile<C, SCRUB>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, ks0, nk, rot, acc);
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int PP, int ABL, int KS, int LD>
-__global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThreads)) void gemm_kernel(MMParams p, int tiles_m, int tiles_n, int vec_store)
+__global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThreads)) void gemm_kernel(MMParams p_in, int tiles_m, int tiles_n, int vec_store, int nwg)
 {
     using C = Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>;
-    __shared__ __attribute__((aligned(16))) uint8_t smem[C::kRingBytes];
+    const MMParams p = pin_params(p_in);  // every kernel argument in one scalar-load clause (fp8mi_common.h)
+    FP8MI_PIN_S(tiles_m); FP8MI_PIN_S(tiles_n); FP8MI_PIN_S(vec_store); FP8MI_PIN_S(nwg);
+    const EpiScalars es = load_epi_scalars(p);  // in flight under the K loop
+    __shared__ __attribute__((aligned(16))) uint8_t smem[C::kRingBytes + kFlagBytes];
+    if (threadIdx.x == 0) *(volatile int *)(smem + C::kRingBytes) = 0;  // NaN verdict word (ordered by the K loop's barriers)
 
     unsigned long long k0_ = 0, k1_ = 0, k2_ = 0; (void)k0_; (void)k1_; (void)k2_;
     STAMP(k0_);
 #ifdef FP8MI_STAMP
     const unsigned long long r0_ = __builtin_amdgcn_s_memrealtime();
 #endif
-    // ---- XCD-aware, bijective block -> tile map ------------------------
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int wg_all = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    // split-K: the grid is p.split copies of the tile grid, K slice slowest (the workgroups an XCD runs at one
-    // time then share one K range of A and B)
+    int tile_m, tile_n, kslice, wg;
+    tile_of_block(blockIdx.x, nwg, tiles_m, tiles_n, tile_m, tile_n, kslice, wg);  // XCD-aware, grouped order (fp8mi_gemm_epi.h)
     const int n_tiles = tiles_m * tiles_n;
-    const int kslice = wg_all / n_tiles, wg = wg_all - kslice * n_tiles;
-    // Grouped order: kGroupM m-tiles x all n-tiles per group, m fastest inside a group.  The 32 tiles an XCD
-    // runs at one time then form a 4 x 8 block whose A and B panels share its 4 MiB L2, instead of 16 x 2
-    // (all of A per round): M=N=K=8192 bf16 492 -> 454 us, FLUX and the 128x128 shard -1..2 %.
-    constexpr int kGroupM = 4;
-    const int per_group = kGroupM * tiles_n;
-    const int group = wg / per_group, first_m = group * kGroupM;
-    const int gm = min(kGroupM, tiles_m - first_m);  // last group may be narrower: the map stays bijective
-    const int in_group = wg - group * per_group;
-    const int tile_m = first_m + in_group % gm, tile_n = in_group / gm;
     const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
 
     const int lane = threadIdx.x & 63;
@@ -536,98 +447,40 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThr
     const int nsplit = p.split > 1 ? p.split : 1;
     const int nk_slice = (nk_all + nsplit - 1) / nsplit;           // the host made every slice non-empty
     const int ks0 = kslice * nk_slice, nk = min(nk_slice, nk_all - ks0);
-    const int rot = (int)(((int64_t)tile_m * nk) / tiles_m);       // in [0, nk)
+    // K is always walked from 0: every tile kernel then adds the K-steps of an output element in the same order, so the
+    // unsplit result does not depend on the tile shape or on where the tile sits (a sharded linear equals the unsharded one
+    // bit for bit); a per-m-tile rotated start measured within +-2 % of this
+    const int rot = 0;
 
     f32x4 acc[C::TN][C::TM];
     run_tile_any<C, false>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, ks0, nk, rot, acc);
 
-    if (p.nan_zero) {
-        int bad = 0;
-#pragma unroll
-        for (int tn = 0; tn < C::TN; ++tn)
-#pragma unroll
-            for (int tm = 0; tm < C::TM; ++tm)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bad |= (acc[tn][tm][j] != acc[tn][tm][j]) ? 1 : 0;
-        // block-wide OR through the (now idle) staging buffer: no second LDS object
-        volatile int *flag = (volatile int *)smem;
-        if (threadIdx.x == 0) *flag = 0;
-        __syncthreads();
-        if (bad) *flag = 1;
-        __syncthreads();
-        const int any_bad = *flag;
-        __syncthreads();
-        if (any_bad) run_tile_any<C, true>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, ks0, nk, rot, acc);
+    // ---- end of the K loop: one barrier frees the ring and carries the NaN verdict (fp8mi_gemm_epi.h) ----
+    volatile int *flag = (volatile int *)(smem + C::kRingBytes);
+    if (p.nan_zero && acc_has_nan<C>(acc)) *flag = 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (p.nan_zero && *flag) {  // workgroup-uniform: redo the tile with every fragment scrubbed (reference NaN semantics)
+        run_tile_any<C, true>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, ks0, nk, rot, acc);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 
-    // ---- split-K: exchange fp32 partial tiles through the workspace; the LAST workgroup of a tile to arrive
-    //      adds all slices in slice order (its own included, re-read like the others: the sum does not depend
-    //      on who arrived last, results are reproducible run to run) and runs the epilogue.  Nobody waits.
+    // ---- split-K: partial tiles meet in the workspace; only the last-arriving slice runs the epilogue ----
     if (nsplit > 1) {
-        // Partials cross XCDs (each has its own L2), so they are written and read with sc0 sc1 (system-coherent:
-        // write-through / miss-always) accesses instead of being published with __threadfence(): the fence is a
-        // whole-L2 write-back + invalidate per wave, which cost 40-60 us per launch here.
-        constexpr int kCoherent = 17;  // aux bits: sc0 | sc1
-        int *counters = (int *)p.ws;
-        constexpr int kVecPerWg = C::TN * C::TM * C::kThreads;      // f32x4 per partial tile (register order)
-        __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(p.ws + kWsCounterBytes), 0, (int)min(p.ws_bytes - kWsCounterBytes, (int64_t)0x7FFFFFFF), 0x00020000);
-        const uint32_t slice_bytes = (uint32_t)n_tiles * kVecPerWg * 16u;
-        const uint32_t my_off = ((uint32_t)wg * kVecPerWg + threadIdx.x) * 16u;  // launch() keeps all offsets < 2^31
-#pragma unroll
-        for (int tn = 0; tn < C::TN; ++tn)
-#pragma unroll
-            for (int tm = 0; tm < C::TM; ++tm)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[tn][tm]), rw,
-                                                       (int)(my_off + (tn * C::TM + tm) * C::kThreads * 16u),
-                                                       (int)((uint32_t)kslice * slice_bytes), kCoherent);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's partial has reached memory ...
-        volatile int *flag = (volatile int *)smem;
-        __syncthreads();  // ... and so has every other thread's, before the workgroup's arrival is counted
-        if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(&counters[wg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __syncthreads();
-        const int arrived = *flag;
-        if (arrived != nsplit - 1) return;  // workgroup-uniform; nobody waits for anybody
-        // kBatch slices' loads are in flight together (each is a miss-always read of another XCD's write: one
-        // round trip per slice when issued one after the other - 8 slices cost ~5 us); the additions stay in slice order
-        constexpr int kQuads = C::TN * C::TM;
-        constexpr int kBatch = kQuads <= 4 ? 4 : (kQuads <= 8 ? 3 : (kQuads <= 16 ? 2 : 1));
-        for (int s0 = 0; s0 < nsplit; s0 += kBatch) {
-            f32x4 v[kBatch][C::TN][C::TM];
-#pragma unroll
-            for (int b = 0; b < kBatch; ++b) {
-                const int s2 = min(s0 + b, nsplit - 1);  // past the end: re-read the last slice (not added)
-#pragma unroll
-                for (int tn = 0; tn < C::TN; ++tn)
-#pragma unroll
-                    for (int tm = 0; tm < C::TM; ++tm)
-                        v[b][tn][tm] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                            rw, (int)(my_off + (tn * C::TM + tm) * C::kThreads * 16u), (int)((uint32_t)s2 * slice_bytes), kCoherent));
-            }
-#pragma unroll
-            for (int b = 0; b < kBatch; ++b) {
-                if (s0 + b < nsplit) {
-#pragma unroll
-                    for (int tn = 0; tn < C::TN; ++tn)
-#pragma unroll
-                        for (int tm = 0; tm < C::TM; ++tm) acc[tn][tm] = (s0 + b == 0) ? v[b][tn][tm] : acc[tn][tm] + v[b][tn][tm];
-                }
-            }
-        }
-        if (threadIdx.x == 0) __hip_atomic_store(&counters[wg], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // zero for the next launch
-        __syncthreads();  // the flag word is part of the ring the staged epilogue reuses
+        if (!splitk_combine<C>(p, acc, smem, wg, kslice, nsplit, n_tiles)) return;
     }
 
     STAMP(k1_);
     // ---- fused epilogue ---------------------------------------------------
     const int rows_m = (int)rows_a, cols_n = (int)rows_b;  // valid extent of this tile
     if (rows_m == BM && cols_n == BN && vec_store) {  // interior tile, 16-byte aligned rows: line-coalesced stores
-        if (p.out_dtype == FP8MI_F32) epilogue_staged<C, FP8MI_F32>(p, acc, smem, m0, n0, wave, wm0, wn0, lane);
-        else if (p.out_dtype == FP8MI_BF16) epilogue_staged<C, FP8MI_BF16>(p, acc, smem, m0, n0, wave, wm0, wn0, lane);
-        else epilogue_staged<C, FP8MI_F16>(p, acc, smem, m0, n0, wave, wm0, wn0, lane);
-    } else if (p.out_dtype == FP8MI_F32) epilogue<C, FP8MI_F32>(p, acc, m0, n0, wm0, wn0, fr, fg, rows_m, cols_n, vec_store);
-    else if (p.out_dtype == FP8MI_BF16) epilogue<C, FP8MI_BF16>(p, acc, m0, n0, wm0, wn0, fr, fg, rows_m, cols_n, vec_store);
-    else epilogue<C, FP8MI_F16>(p, acc, m0, n0, wm0, wn0, fr, fg, rows_m, cols_n, vec_store);
+        if (p.out_dtype == FP8MI_F32) epilogue_staged<C, FP8MI_F32>(p, es, acc, smem, m0, n0, wave, wm0, wn0, lane);
+        else if (p.out_dtype == FP8MI_BF16) epilogue_staged<C, FP8MI_BF16>(p, es, acc, smem, m0, n0, wave, wm0, wn0, lane);
+        else epilogue_staged<C, FP8MI_F16>(p, es, acc, smem, m0, n0, wave, wm0, wn0, lane);
+    } else if (p.out_dtype == FP8MI_F32) epilogue<C, FP8MI_F32>(p, es, acc, m0, n0, wm0, wn0, fr, fg, rows_m, cols_n, vec_store);
+    else if (p.out_dtype == FP8MI_BF16) epilogue<C, FP8MI_BF16>(p, es, acc, m0, n0, wm0, wn0, fr, fg, rows_m, cols_n, vec_store);
+    else epilogue<C, FP8MI_F16>(p, es, acc, m0, n0, wm0, wn0, fr, fg, rows_m, cols_n, vec_store);
 #ifdef FP8MI_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(k2_);
@@ -635,6 +488,8 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThr
         g_stamp[blockIdx.x * 32 + 5] = k1_ - k0_;   // entry .. end of K loop (incl. NaN check)
         g_stamp[blockIdx.x * 32 + 6] = k2_ - k1_;   // epilogue incl. store drain
         g_stamp[blockIdx.x * 32 + 7] = __builtin_amdgcn_s_memrealtime() - r0_;  // 100 MHz ticks over the whole tile
+        g_stamp[blockIdx.x * 32 + 29] = k0_;
+        g_stamp[blockIdx.x * 32 + 30] = k1_;
     }
 #endif
 }
@@ -646,33 +501,14 @@ int launch(const MMParams &p_in, hipStream_t s)
     MMParams p = p_in;
     const int64_t tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     if (tm * tn > 0x7FFFFFFF) return FP8MI_E_UNSUPPORTED;
-    {   // split-K: clamp to what K and the workspace allow; every slice gets at least one ring stage
-        const int64_t nk_all = (p.K + BK * C::KS - 1) / (BK * C::KS);
-        int64_t split = p.split > 1 ? p.split : 1;
-        if (p.split == 0 && tm * tn <= 128 && nk_all >= 8) {
-            // auto: the tile grid leaves at least half of the 256 CUs idle and K is deep - slice K so that the
-            // grid fills the chip, at least 4 ring stages per slice (measured: M=128 K=14336 N=4096 49 -> ~20 us)
-            split = 256 / (tm * tn);
-            if (split > nk_all / 4) split = nk_all / 4;
-            if (split > 16) split = 16;
-        }
-        if (!p.ws || tm * tn > kWsCounterBytes / 4) split = 1;
-        if (split > nk_all) split = nk_all > 0 ? nk_all : 1;
-        if (split > 1) {
-            const int64_t per = (nk_all + split - 1) / split;
-            split = (nk_all + per - 1) / per;  // drop empty slices (the kernel re-derives `per` from this count)
-            if (tm * tn * split > 0x7FFFFFFF) return FP8MI_E_UNSUPPORTED;
-            const int64_t need = kWsCounterBytes + split * tm * tn * (int64_t)BM * BN * 4;
-            if (need > p.ws_bytes || need > 0x7FFFFFFF) split = 1;  // (the kernel addresses partials with 32-bit offsets)
-        }
-        p.split = (int)split;
-    }
+    const int rc = resolve_split(p, tm, tn, BM, BN, BK * C::KS);
+    if (rc) return rc;
     const int esz = p.out_dtype == FP8MI_F32 ? 4 : 2;
     // 16-byte aligned rows and 4-element groups: enables the vector stores of both epilogues
     const int vec = (((p.ldc * esz) % 16) == 0 && (((uintptr_t)p.C) % 16) == 0) ? 1 : 0;
-    FP8MI_LAUNCH((gemm_kernel<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>), dim3((unsigned)(tm * tn * p.split)), dim3(C::kThreads), s, p, (int)tm,
-                       (int)tn, vec);
-    return (int)hipGetLastError();
+    const unsigned grid = (unsigned)(tm * tn * p.split);
+    return fp8mi_launch(gemm_kernel<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>, dim3(grid), dim3(C::kThreads), s, p, (int)tm, (int)tn, vec,
+                        (int)grid);
 }
 
 }  // namespace
@@ -699,6 +535,8 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
         //   256x256: 8 + 1.6 nk      128x128: 5.5 + 0.87 nk      128x64: 5 + 0.37 nk        (nk = K / 128)
         // e.g. FLUX 4096x3072x12288: 139 / 158 / 332 -> 256x256; 6144^3: 229 / 227 -> 128x128 (2.25 rounds of
         // 256x256 tiles waste most of the third); C3 512x4096x4096: one round of 128x64 tiles, 16.8.
+        // The CU count is the device's (a CPX partition has 32): only the slots per round depend on it.
+        const double cus = (double)fp8mi_cu_count();
         const double nk = (double)((p.K + 127) / 128);
         auto rounds = [](double tiles, double slots, double a, double b) {  // a partly filled round costs a + b x fill
             const double r = tiles / slots, whole = (double)(int64_t)r, part = r - whole;
@@ -707,10 +545,10 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
         const double t256 = (double)(((p.M + 255) / 256) * ((p.N + 255) / 256));
         const double t128 = (double)(((p.M + 127) / 128) * ((p.N + 127) / 128));
         const double t64 = (double)(((p.M + 127) / 128) * ((p.N + 63) / 64));
-        const double us256 = rounds(t256, 256, 0.75, 0.25) * (8.0 + 1.6 * nk);   // (a quarter-filled round of 256x256
-        const double us128 = rounds(t128, 512, 0.55, 0.45) * (5.5 + 0.87 * nk);  //  tiles still costs 0.8 of a full one)
-        const double us64 = rounds(t64, 256, 0.6, 0.4) * (5.0 + 0.37 * nk);
-        if (t64 <= 128) {
+        const double us256 = rounds(t256, cus, 0.75, 0.25) * (8.0 + 1.6 * nk);       // (a quarter-filled round of 256x256
+        const double us128 = rounds(t128, 2 * cus, 0.55, 0.45) * (5.5 + 0.87 * nk);  //  tiles still costs 0.8 of a full one)
+        const double us64 = rounds(t64, cus, 0.6, 0.4) * (5.0 + 0.37 * nk);
+        if (t64 <= cus / 2) {
             // few tiles: one per CU at most, split-K (launch<>) fills the rest of the chip when a workspace came along;
             // with few rows of A the tile is better spent on N
             variant = (p.M <= 64 && p.ws && p.split != 1) ? FP8MI_KERNEL_GEMM_64x128 : FP8MI_KERNEL_GEMM_128x64;
@@ -719,11 +557,23 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
         else variant = FP8MI_KERNEL_GEMM_128x64;
     }
     switch (variant) {
-    case FP8MI_KERNEL_GEMM_128: return launch<128, 128, 64, 32, 2, 0, 0, 1, 4>(p, s);  // 8 waves (0-3 load), 2 x 32 KiB: 2 workgroups / CU
-    case FP8MI_KERNEL_GEMM_128x64: return launch<128, 64, 32, 32, 3, 0, 0, 2, 4>(p, s);  // 8 waves (0-3 load), 3 x 48 KiB ring, 2 K-steps per stage
-    case FP8MI_KERNEL_GEMM_256: return launch<256, 256, 128, 64, 2, 0, 0, 1, 4>(p, s);  // 8 waves (0-3 load), 2 x 64 KiB
-    case FP8MI_KERNEL_GEMM_64x128: return launch<64, 128, 32, 32, 3, 0, 0, 2, 4>(p, s);  // 8 waves (0-3 load), 3 x 48 KiB, for M <= 64
-    // schedule variants kept for A/B timing (same results): tools/bq.sh <workload> <id>
+    // product kernels: 8 waves, waves 0-3 (one per SIMD) issue the stage DMA (template: BM, BN, WM, WN, ring stages, loop order,
+    // -, K-steps per stage, loading waves).  Loop orders (run_tile / run_tile_staggered): the small tiles issue their fragment reads
+    // ahead of the stage DMA (C3 15.9 -> 15.3 us); the 256x256 tile runs its two wave groups half a K-step apart (FLUX 130 -> 124 us,
+    // 8192^3 509 -> 479 us); for the 128x128 tile neither order is a consistent gain (shard +1.6 %, 8192^3 -4.5 %): it keeps the plain one.
+    case FP8MI_KERNEL_GEMM_128: return launch<128, 128, 64, 32, 2, 0, 0, 1, 4>(p, s);   // 2 x 32 KiB ring: 2 workgroups / CU
+    case FP8MI_KERNEL_GEMM_128x64: return launch<128, 64, 32, 32, 3, 1, 0, 2, 4>(p, s);  // 3 x 48 KiB ring, 2 K-steps per stage
+    case FP8MI_KERNEL_GEMM_256: return launch<256, 256, 128, 64, 2, 2, 0, 1, 4>(p, s);   // 2 x 64 KiB ring, staggered wave groups
+    case FP8MI_KERNEL_GEMM_64x128: return launch<64, 128, 32, 32, 3, 1, 0, 2, 4>(p, s);  // 3 x 48 KiB ring, for M <= 64
+#ifdef FP8MI_DIAG  // schedule variants kept for A/B timing (diagnostic library only; same results): tools/ab_kernels.py
+    case 30: return launch<256, 256, 128, 64, 2, 1, 0, 1, 4>(p, s);            // 256x256, fragment reads before the stage DMA
+    case 31: return launch<128, 128, 64, 32, 2, 1, 0, 1, 4>(p, s);             // 128x128, same
+    case 32: return launch<128, 64, 32, 32, 3, 0, 0, 2, 4>(p, s);              // 128x64, stage DMA first (the round-1 order)
+    case 33: return launch<256, 256, 128, 64, 2, 1>(p, s);                     // 256x256 reads first, all 8 waves load
+    case 34: return launch<256, 256, 128, 64, 2, 0, 0, 1, 4>(p, s);            // 256x256, lockstep (the round-1 order)
+    case 35: return launch<256, 256, 128, 64, 2, 2>(p, s);                     // 256x256, staggered, all waves load
+    case 36: return launch<128, 128, 64, 32, 2, 2, 0, 1, 4>(p, s);             // 128x128, staggered, waves 0-3 load
+    case 37: return launch<128, 128, 64, 32, 2, 2>(p, s);                      // 128x128, staggered, all waves load
     case 7: return launch<128, 64, 64, 32, 6>(p, s);                           // 128x64, 4 waves
     case 8: return launch<128, 128, 64, 64, 4>(p, s);                          // 128x128, 4 waves, 4-stage ring
     case 9: return launch<256, 128, 64, 64, 3, 0, 0, 1, 4>(p, s);              // 256x128, 8 waves (0-3 load), 3 x 48 KiB
@@ -731,19 +581,6 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     case 11: return launch<256, 256, 128, 64, 2>(p, s);                        // 256x256, all 8 waves load
     case 12: return launch<128, 64, 32, 32, 3, 0, 0, 2>(p, s);                 // 128x64 KS=2, all 8 waves load
     case 13: return launch<128, 128, 64, 32, 2>(p, s);                         // 128x128, all 8 waves load
-#ifdef FP8MI_ABLATE  // diagnostic library only: 10x = 128x64 8-wave, 11x = 256x256; x = ablation bits
-    case 101: return launch<128, 64, 32, 32, 6, 0, 1>(p, s);
-    case 102: return launch<128, 64, 32, 32, 6, 0, 2>(p, s);
-    case 104: return launch<128, 64, 32, 32, 6, 0, 4>(p, s);
-    case 103: return launch<128, 64, 32, 32, 6, 0, 3>(p, s);
-    case 105: return launch<128, 64, 32, 32, 6, 0, 5>(p, s);
-    case 106: return launch<128, 64, 32, 32, 6, 0, 6>(p, s);
-    case 111: return launch<256, 256, 128, 64, 2, 0, 1>(p, s);
-    case 112: return launch<256, 256, 128, 64, 2, 0, 2>(p, s);
-    case 114: return launch<256, 256, 128, 64, 2, 0, 4>(p, s);
-    case 113: return launch<256, 256, 128, 64, 2, 0, 3>(p, s);
-    case 115: return launch<256, 256, 128, 64, 2, 0, 5>(p, s);
-    case 116: return launch<256, 256, 128, 64, 2, 0, 6>(p, s);
 #endif
     default: return FP8MI_E_ENUM;
     }

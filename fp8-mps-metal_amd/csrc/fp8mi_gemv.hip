@@ -40,8 +40,14 @@ FP8MI_DEVICE void decode16(const u32x4 &w, f32x2 (&f)[8])
 }
 
 template <int STEPS, int RB, bool NT = true, int kWaves = 4>
-__global__ __launch_bounds__(kWaves * 64) void gemv_kernel(MMParams p)
+__global__ __launch_bounds__(kWaves * 64) void gemv_kernel(MMParams p_in)
 {
+    const MMParams p = pin_params(p_in);  // every kernel argument in one scalar-load clause (fp8mi_common.h)
+    // epilogue scalars: fetched now, under the weight stream (loaded where they are used they were a dependent global load
+    // between the reduction and the store)
+    const float sr = p.scale_result ? p.scale_result[0] : 1.0f;
+    const float sx = p.scale_a[0];
+    const float sw0 = p.scale_b[0];
     constexpr int kThreads = kWaves * 64;
     __shared__ float part[kWaves][RB];
     __shared__ int dirty_rows[RB];
@@ -112,8 +118,6 @@ __global__ __launch_bounds__(kWaves * 64) void gemv_kernel(MMParams p)
     }
     __syncthreads();
 
-    const float sr = p.scale_result ? p.scale_result[0] : 1.0f;
-    const float sx = p.scale_a[0];
     int dirty = 0;
     if (threadIdx.x < RB) {
         const int r = threadIdx.x;
@@ -124,9 +128,9 @@ __global__ __launch_bounds__(kWaves * 64) void gemv_kernel(MMParams p)
         dirty = (p.nan_zero && sum != sum) ? 1 : 0;
         dirty_rows[r] = dirty;
         if (n < p.N && !dirty) {
-            const float sw = p.sb_row ? p.scale_b[n] : p.scale_b[0];
-            const float b = p.bias ? load_as_float(p.bias, n, p.bias_dtype) : 0.0f;
-            store_from_float(p.C, n, epilogue_value(sum, sx, sw, p.bias != nullptr, b, p.scale_result != nullptr, sr),
+            const float sw = p.sb_row ? p.scale_b[n] : sw0;
+            const float b = p.bias ? load_as_float(p.bias, p.transposed ? 0 : n, p.bias_dtype) : 0.0f;
+            store_from_float(p.C, n, epilogue_value(sum, sx, sw, p.bias != nullptr, b, p.scale_result != nullptr, sr, p.transposed != 0),
                              p.out_dtype);
         }
     }
@@ -147,9 +151,9 @@ __global__ __launch_bounds__(kWaves * 64) void gemv_kernel(MMParams p)
             float sum = 0.0f;
 #pragma unroll
             for (int wv = 0; wv < kWaves; ++wv) sum += part[wv][0];
-            const float sw = p.sb_row ? p.scale_b[n] : p.scale_b[0];
-            const float b = p.bias ? load_as_float(p.bias, n, p.bias_dtype) : 0.0f;
-            store_from_float(p.C, n, epilogue_value(sum, sx, sw, p.bias != nullptr, b, p.scale_result != nullptr, sr),
+            const float sw = p.sb_row ? p.scale_b[n] : sw0;
+            const float b = p.bias ? load_as_float(p.bias, p.transposed ? 0 : n, p.bias_dtype) : 0.0f;
+            store_from_float(p.C, n, epilogue_value(sum, sx, sw, p.bias != nullptr, b, p.scale_result != nullptr, sr, p.transposed != 0),
                              p.out_dtype);
         }
     }
@@ -159,8 +163,7 @@ template <int STEPS, int RB, bool NT = true, int kWaves = 4>
 int launch(const MMParams &p, hipStream_t s)
 {
     const int64_t grid = (p.N + RB - 1) / RB;
-    FP8MI_LAUNCH((gemv_kernel<STEPS, RB, NT, kWaves>), dim3((unsigned)grid), dim3(kWaves * 64), s, p);
-    return (int)hipGetLastError();
+    return fp8mi_launch(gemv_kernel<STEPS, RB, NT, kWaves>, dim3((unsigned)grid), dim3(kWaves * 64), s, p);
 }
 
 }  // namespace
@@ -181,7 +184,7 @@ int fp8mi_launch_gemv(const MMParams &p, hipStream_t s)
     // workgroups (K = 14336, N = 4096: 14.5 vs 15.5 us; K = 12288, N = 3072: 11.8 vs 10.4 us)
     if (steps <= 1) return launch<1, 4>(p, s);
     if (steps <= 2) return launch<2, 4>(p, s);
-    if ((p.N + 7) / 8 < 448) return launch<4, 4>(p, s);
+    if ((p.N + 7) / 8 < (7 * (int64_t)fp8mi_cu_count()) / 4) return launch<4, 4>(p, s);
     if (p.K > 16384) return launch<2, 4, true, 8>(p, s);  // 8 waves x 2 steps, loops over 16-KiB chunks (K = 28672, N = 8192: 41 vs 44.6 us)
     return launch<4, 8>(p, s);
 }

@@ -34,10 +34,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void generic_kernel(MMParams p
     if (lane == 0) {
         const float sa = p.sa_row ? p.scale_a[m] : p.scale_a[0];
         const float sb = p.sb_row ? p.scale_b[n] : p.scale_b[0];
-        const float bias = p.bias ? load_as_float(p.bias, n, p.bias_dtype) : 0.0f;
+        const float bias = p.bias ? load_as_float(p.bias, p.transposed ? m : n, p.bias_dtype) : 0.0f;
         const float sr = p.scale_result ? p.scale_result[0] : 1.0f;
         store_from_float(p.C, m * p.ldc + n,
-                         epilogue_value(s, sa, sb, p.bias != nullptr, bias, p.scale_result != nullptr, sr), p.out_dtype);
+                         epilogue_value(s, sa, sb, p.bias != nullptr, bias, p.scale_result != nullptr, sr, p.transposed != 0), p.out_dtype);
     }
 }
 
@@ -49,6 +49,5 @@ int fp8mi_launch_generic(const MMParams &p, hipStream_t s)
     const int64_t gy = p.M < 65535 ? p.M : 65535;
     const int64_t gz = (p.M + 65534) / 65535;
     if (gx > 0x7FFFFFFF || gz > 65535) return FP8MI_E_UNSUPPORTED;
-    FP8MI_LAUNCH(generic_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)gz), dim3(kWavesPerBlock * 64), s, p);
-    return (int)hipGetLastError();
+    return fp8mi_launch(generic_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)gz), dim3(kWavesPerBlock * 64), s, p);
 }

@@ -24,8 +24,9 @@ namespace {
 constexpr int kScaleOne = 0x7F7F7F7F;
 
 template <int TM, int kU /* K-steps per wave in flight */, int KW /* waves per workgroup = K shares of its fragment */>
-__global__ __launch_bounds__(KW * 64) void skinny_kernel(MMParams p)
+__global__ __launch_bounds__(KW * 64) void skinny_kernel(MMParams p_in)
 {
+    const MMParams p = pin_params(p_in);  // every kernel argument in one scalar-load clause (fp8mi_common.h)
     __shared__ f32x4 part[KW][TM][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -101,8 +102,8 @@ __global__ __launch_bounds__(KW * 64) void skinny_kernel(MMParams p)
         for (int j = 0; j < 4; ++j) {
             const int64_t nj = min(n + j, p.N - 1);
             const float sb = p.sb_row ? p.scale_b[nj] : p.scale_b[0];
-            const float b = has_bias ? load_as_float(p.bias, nj, p.bias_dtype) : 0.0f;
-            v[j] = epilogue_value(s[j], sa, sb, has_bias, b, has_sr, sr);
+            const float b = has_bias ? load_as_float(p.bias, p.transposed ? m : nj, p.bias_dtype) : 0.0f;
+            v[j] = epilogue_value(s[j], sa, sb, has_bias, b, has_sr, sr, p.transposed != 0);
         }
         const int64_t idx = m * p.ldc + n;
         if (vec_ok && n + 3 < p.N && p.out_dtype == FP8MI_F32) {
@@ -119,8 +120,7 @@ template <int TM, int kU, int KW>
 int launch_kw(const MMParams &p, hipStream_t s)
 {
     const int64_t grid = (p.N + 15) / 16;
-    FP8MI_LAUNCH((skinny_kernel<TM, kU, KW>), dim3((unsigned)grid), dim3(KW * 64), s, p);
-    return (int)hipGetLastError();
+    return fp8mi_launch(skinny_kernel<TM, kU, KW>, dim3((unsigned)grid), dim3(KW * 64), s, p);
 }
 
 template <int TM, int kU>

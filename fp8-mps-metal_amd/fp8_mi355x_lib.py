@@ -38,6 +38,7 @@ ENC_REFERENCE, ENC_RNE = 0, 1
 KERNEL_AUTO, KERNEL_GEMV, KERNEL_GEMM_128, KERNEL_GENERIC, KERNEL_GEMM_256, KERNEL_GEMM_128x64, KERNEL_SKINNY = range(7)
 KERNEL_GEMM_64x128 = 14
 WS_COUNTER_BYTES = 4096
+EPILOGUE_TRANSPOSED = 0x100  # OR into bias_dtype (include/fp8mi.h)
 
 _vp, _i64, _int = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
 
@@ -60,6 +61,7 @@ SIGNATURES = {
     "fp8mi_scaled_mm_ws": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64,
                                   _int, _int, _int, _int, _int, _int, _int, _vp, _i64, _vp]),
     "fp8mi_scaled_mm_workspace_bytes": (_i64, []),
+    "fp8mi_workspace_reset": (_int, [_vp, _i64, _vp]),
     "fp8mi_dequant": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
     "fp8mi_encode": (_int, [_vp, _int, _vp, _vp, _i64, _int, _vp]),
     "fp8mi_amax": (_int, [_vp, _int, _vp, _i64, _vp]),

@@ -34,6 +34,8 @@ What differs, deliberately:
 
 from __future__ import annotations
 
+import threading
+
 import torch
 
 import fp8_mi355x_lib as _l
@@ -55,15 +57,36 @@ def _stream(device):
 # counters at its head are zeroed once here and left zero by every launch (include/fp8mi.h).  Kept alive for the
 # life of the process, so a pointer captured into a HIP graph stays valid.
 _workspaces: dict = {}
+_workspaces_lock = threading.Lock()
 
 
 def _workspace(device):
+    """The split-K workspace of (device, current stream), or None while that stream is being captured into a HIP graph
+    and no workspace exists yet: allocating inside a capture would put it into the graph's private pool, where later
+    eager launches on the same stream handle would share it (warm the op up once before capturing; without a workspace
+    the call simply does not split K)."""
     key = (device.index, _stream(device))
     ws = _workspaces.get(key)
     if ws is None:
-        ws = torch.zeros(int(_l.load().fp8mi_scaled_mm_workspace_bytes()), dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        with _workspaces_lock:
+            ws = _workspaces.get(key)
+            if ws is None:
+                ws = torch.empty(int(_l.load().fp8mi_scaled_mm_workspace_bytes()), dtype=torch.uint8, device=device)
+                _l.check(_l.load().fp8mi_workspace_reset(ws.data_ptr(), ws.numel(), _stream(device)), "fp8mi_workspace_reset")
+                _workspaces[key] = ws
     return ws
+
+
+def reset_workspaces():
+    """Zero the arrival counters of every cached split-K workspace (include/fp8mi.h, fp8mi_workspace_reset): only needed
+    after a launch was aborted mid-flight (device fault, process-level error recovery) - every completed launch leaves
+    them zero by itself."""
+    with _workspaces_lock:
+        for (dev_index, _), ws in _workspaces.items():
+            with torch.cuda.device(dev_index):
+                _l.check(_l.load().fp8mi_workspace_reset(ws.data_ptr(), ws.numel(), _stream(ws.device)), "fp8mi_workspace_reset")
 
 
 def _to_device(t: torch.Tensor) -> torch.Tensor:
@@ -84,7 +107,8 @@ def _scale_arg(scale, device, rows: int, what: str):
 def fp8_scaled_mm(A: torch.Tensor, B: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,
                   *, bias: torch.Tensor | None = None, scale_result: torch.Tensor | None = None,
                   out_dtype: torch.dtype | None = None, nan_mode: int | None = None,
-                  kernel: int = _l.KERNEL_AUTO, split_k: int = 0) -> torch.Tensor:
+                  kernel: int = _l.KERNEL_AUTO, split_k: int = 0, out: torch.Tensor | None = None,
+                  transposed_epilogue: bool = False) -> torch.Tensor:
     """FP8 scaled matrix multiplication on the GPU.
 
     A: (M, K) uint8 - e4m3fn bytes, row-major
@@ -97,6 +121,12 @@ def fp8_scaled_mm(A: torch.Tensor, B: torch.Tensor, scale_a: torch.Tensor, scale
     picked by shape inside the library (GEMV for M == 1, MFMA GEMM otherwise).
     split_k: 0 lets the library slice K when M x N gives too few tiles to fill
     the GPU (small batch, deep K), 1 forbids it, > 1 forces that many slices.
+    out: optional (M, N) destination of `out_dtype` with unit column stride (any
+    row stride: e.g. a slab of a larger buffer); returned instead of a new tensor.
+    transposed_epilogue: the call computes C^T = W . X^T for a caller whose
+    activations are `B` here (fp8_sharded_linear): `bias` then has M elements and
+    runs along the rows, and the scales are applied in the order of the
+    untransposed product (include/fp8mi.h, FP8MI_EPILOGUE_TRANSPOSED).
     """
     assert A.dtype == torch.uint8 and B.dtype == torch.uint8
     assert A.dim() == 2 and B.dim() == 2
@@ -122,9 +152,15 @@ def fp8_scaled_mm(A: torch.Tensor, B: torch.Tensor, scale_a: torch.Tensor, scale
     out_dtype = torch.float32 if out_dtype is None else out_dtype
     if out_dtype not in _DTYPE_CODE:
         raise AssertionError(f"unsupported out_dtype {out_dtype}")
-    C = torch.empty(M, N, dtype=out_dtype, device=dev)
+    if out is not None:
+        assert out.shape == (M, N) and out.dtype == out_dtype and out.device == dev, "out must be (M, N) out_dtype on A's device"
+        assert N <= 1 or out.stride(1) == 1, "out needs unit column stride"
+        C = out
+    else:
+        C = torch.empty(M, N, dtype=out_dtype, device=dev)
     if M == 0 or N == 0:
         return C
+    ldc = max(C.stride(0), N) if M > 1 else max(N, 1)
 
     bias_ptr, bias_code = None, _l.F32
     if bias is not None:
@@ -132,8 +168,11 @@ def fp8_scaled_mm(A: torch.Tensor, B: torch.Tensor, scale_a: torch.Tensor, scale
         if bias.dtype not in _DTYPE_CODE:
             bias = bias.to(torch.float32)
         bias = bias.reshape(-1).contiguous()
-        assert bias.numel() == N, f"bias has {bias.numel()} elements; expected {N}"
+        nb = M if transposed_epilogue else N
+        assert bias.numel() == nb, f"bias has {bias.numel()} elements; expected {nb}"
         bias_ptr, bias_code = bias.data_ptr(), _DTYPE_CODE[bias.dtype]
+    if transposed_epilogue:
+        bias_code |= _l.EPILOGUE_TRANSPOSED
     sr_ptr = None
     if scale_result is not None:
         scale_result = scale_result.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
@@ -146,7 +185,7 @@ def fp8_scaled_mm(A: torch.Tensor, B: torch.Tensor, scale_a: torch.Tensor, scale
         ws = _workspace(dev) if (split_k != 1 and M > 1 and K >= 1024) else None
         rc = lib.fp8mi_scaled_mm_ws(
             A.data_ptr(), B.data_ptr(), C.data_ptr(), sa.data_ptr(), sb.data_ptr(), bias_ptr, sr_ptr,
-            M, N, K, lda, ldb, N, sa_mode, sb_mode, _DTYPE_CODE[out_dtype], bias_code,
+            M, N, K, lda, ldb, ldc, sa_mode, sb_mode, _DTYPE_CODE[out_dtype], bias_code,
             NAN_MODE if nan_mode is None else nan_mode, kernel, split_k if ws is not None else 1,
             ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream(dev))
     _l.check(rc, "fp8mi_scaled_mm")

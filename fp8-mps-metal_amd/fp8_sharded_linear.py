@@ -14,8 +14,15 @@ Why it shards this way (MI355X-first):
   * Each rank computes the TRANSPOSED block  C^T[rows] = B[rows] . A^T  - free,
     because both operands are K-contiguous and the kernel does not care which
     one is called "A".  The per-rank result (rows, M) is then a contiguous slab
-    of C^T (N, M), so `all_gather_into_tensor` lands the full C^T in place and
-    C is returned as its `.t()` view: no post-gather transpose or copy.
+    of C^T (N, M): the GEMM writes it STRAIGHT into its slot of the gather
+    buffer and the all-gather runs in place; C is returned as the `.t()` view -
+    no staging tensor, no post-gather transpose or copy.
+  * The epilogue stays fused and bit-identical to the single-GPU call: the
+    kernels' transposed-epilogue mode (FP8MI_EPILOGUE_TRANSPOSED) takes the
+    bias per output ROW (= weight row) and applies the scales in the order of
+    the untransposed product, and every tile kernel adds the K-steps of an
+    element in the same order - so a sharded linear returns the bits the
+    unsharded fused `_scaled_mm` returns (tested, bf16 output included).
   * xGMI is point-to-point (7 links per GPU); the all-gather (each rank's slab
     to all 7 peers at once) dominates this shape, so it is pipelined against
     the GEMM: the weight rows are dealt out CHUNK-CYCLICALLY - chunk j of every
@@ -24,11 +31,14 @@ Why it shards this way (MI355X-first):
     implies is applied once, at weight-load time (`shard_rows`), and it is
     chosen so that gathered order == global row order: the result needs no
     un-permutation.
+  * Nothing is created per call besides the output: the side stream and the
+    per-chunk events live in the module, so a forward is `chunks` launches +
+    `chunks` collectives and can be captured into a HIP graph.
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).  The
 local product is the HIP kernel; `mm` can be injected so that the sharding /
 gather logic is testable with gloo on CPU (tests only - the product default
-has no CPU path).
+has no CPU path).  No 2/4/8-GPU measurement exists yet.
 """
 
 from __future__ import annotations
@@ -49,13 +59,11 @@ def shard_rows(N: int, world: int, rank: int, chunks: int = 1) -> torch.Tensor:
     return j * (world * nc) + rank * nc + i
 
 
-def _default_mm(A, B_nk, sa, sb, out_dtype, out=None):
+def _default_mm(w_rows, x_u8, scale_w, scale_x, bias, out):
+    """out (rows, M) <- the transposed product W[rows] . X^T with the fused epilogue of the untransposed call."""
     import fp8_mi355x_native as native
-    r = native.fp8_scaled_mm(A, B_nk, sa, sb, out_dtype=out_dtype)
-    if out is not None:
-        out.copy_(r)
-        return out
-    return r
+    return native.fp8_scaled_mm(w_rows, x_u8, scale_w, scale_x, bias=bias, out_dtype=out.dtype, out=out,
+                                transposed_epilogue=True, split_k=1)
 
 
 class ColumnShardedFP8Linear:
@@ -65,6 +73,7 @@ class ColumnShardedFP8Linear:
                 `shard_rows(N, world, rank, chunks)` order
     scale_b   : [1] or [N/world] (per local row, same order)
     bias      : None or [N/world] (same order)
+    mm        : tests only - `mm(w_rows, x_u8, scale_w, scale_x, bias_or_None, out)` filling `out` (rows, M)
     """
 
     def __init__(self, weight_u8, scale_b, bias=None, *, N: int, group=None, chunks: int = 1,
@@ -72,16 +81,28 @@ class ColumnShardedFP8Linear:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if chunks < 1 or N % (self.world * chunks):
+            raise ValueError(f"N={N} must be divisible by world*chunks={self.world * chunks}")
         self.N, self.chunks, self.out_dtype = N, chunks, out_dtype
         self.nl = N // self.world
         self.nc = self.nl // chunks
-        if weight_u8.shape[0] != self.nl or weight_u8.dtype != torch.uint8:
+        if weight_u8.dim() != 2 or weight_u8.shape[0] != self.nl or weight_u8.dtype != torch.uint8:
             raise ValueError(f"weight shard must be ({self.nl}, K) uint8")
         self.w = weight_u8
         self.scale_b = scale_b.reshape(-1)
+        if self.scale_b.numel() not in (1, self.nl):
+            raise ValueError(f"scale_b has {self.scale_b.numel()} elements; expected 1 or {self.nl}")
         self.bias = None if bias is None else bias.reshape(-1)
+        if self.bias is not None and self.bias.numel() != self.nl:
+            raise ValueError(f"bias has {self.bias.numel()} elements; expected {self.nl}")
         self.mm = mm or _default_mm
+        # per-chunk views, made once
+        self._w = [self.w[j * self.nc:(j + 1) * self.nc] for j in range(chunks)]
+        self._sb = [self.scale_b[j * self.nc:(j + 1) * self.nc] if self.scale_b.numel() == self.nl else self.scale_b
+                    for j in range(chunks)]
+        self._bias = [None if self.bias is None else self.bias[j * self.nc:(j + 1) * self.nc] for j in range(chunks)]
         self._comm_stream = None
+        self._events = None
 
     @classmethod
     def from_full(cls, weight_u8_full, scale_b, bias=None, *, group=None, chunks=1, **kw):
@@ -106,30 +127,27 @@ class ColumnShardedFP8Linear:
         on_gpu = dev.type == "cuda" and grouped
         if on_gpu and self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=dev)
+            self._events = [torch.cuda.Event() for _ in range(self.chunks)]
+        cur = torch.cuda.current_stream(dev) if on_gpu else None
+        span = self.world * self.nc
         handles = []
         for j in range(self.chunks):
-            lo, hi = j * self.nc, (j + 1) * self.nc
-            sb = self.scale_b[lo:hi] if self.scale_b.numel() == self.nl else self.scale_b
-            # transposed product: the weight rows play "A", the activations play "B_nk"
-            part = self.mm(self.w[lo:hi], x_u8, sb, scale_a, self.out_dtype)
-            if self.bias is not None:
-                part.add_(self.bias[lo:hi].to(part.dtype)[:, None])
-            block = out_t[j * self.world * self.nc:(j + 1) * self.world * self.nc]
+            block = out_t[j * span:(j + 1) * span]                     # chunk j of every rank, in rank order
+            slot = block[self.rank * self.nc:(self.rank + 1) * self.nc]  # ... this rank's part: the GEMM's destination
+            self.mm(self._w[j], x_u8, self._sb[j], scale_a, self._bias[j], slot)
             if not grouped:
-                block.copy_(part)
-            elif on_gpu:
-                ev = torch.cuda.Event()
-                ev.record()
+                continue                                               # single process: the slot IS the result
+            if on_gpu:
+                self._events[j].record(cur)
+                self._comm_stream.wait_event(self._events[j])
                 with torch.cuda.stream(self._comm_stream):
-                    self._comm_stream.wait_event(ev)
-                    dist.all_gather_into_tensor(block, part, group=self.group)
-                    part.record_stream(self._comm_stream)
+                    dist.all_gather_into_tensor(block, slot, group=self.group)   # in place: slot is block[rank]
             else:
-                handles.append(dist.all_gather_into_tensor(block, part.contiguous(), group=self.group, async_op=True))
+                handles.append(dist.all_gather_into_tensor(block, slot, group=self.group, async_op=True))
         for h in handles:
             h.wait()
         if on_gpu:
-            torch.cuda.current_stream(dev).wait_stream(self._comm_stream)
+            cur.wait_stream(self._comm_stream)
         return out_t.t()
 
     __call__ = forward

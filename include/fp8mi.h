@@ -17,8 +17,12 @@
  *   - return value 0 = ok; negative = argument error (FP8MI_E_*); positive =
  *     a hipError_t from the launch.  fp8mi_last_error() returns a
  *     thread-local, human-readable message for the last non-zero return;
- *   - the library is stateless (no globals besides that message), so calls
- *     are re-entrant from any thread;
+ *   - the compute entry points keep no state (no globals besides that message
+ *     and a per-device cache of the CU count), so calls are re-entrant from any
+ *     thread.  The two measurement hooks at the end of this header
+ *     (fp8mi_profile_begin / _end) DO keep per-thread state - an event pool and
+ *     an "a profile is open" flag that every launch on that thread consults;
+ *     they exist for bench.py and are not meant for production call paths;
  *   - all element counts are 64-bit (the reference's `uint count`,
  *     fp8_matmul.metal:218,231, caps at 2^32-1).
  *
@@ -37,10 +41,18 @@
 extern "C" {
 #endif
 
-#define FP8MI_VERSION 0x000200 /* 0.2.0: + split-K workspace entry point */
+#define FP8MI_VERSION 0x000300 /* 0.3.0: + fp8mi_workspace_reset, FP8MI_EPILOGUE_TRANSPOSED */
 
 /* element types of non-fp8 operands */
 enum { FP8MI_F32 = 0, FP8MI_F16 = 1, FP8MI_BF16 = 2 };
+
+/* OR into `bias_dtype`: the caller computes the TRANSPOSED product C^T = B . A^T (what a
+ * rank of an N-column-sharded linear does, so that its block of the output is contiguous:
+ * the weight shard is passed as `A`, the activations as `B_nk`).  The epilogue then
+ * multiplies by scale_b first and scale_a second and takes bias[m] (M elements, per
+ * output row) - bit for bit what the untransposed fused epilogue
+ * ((acc * s_activation) * s_weight + bias[weight row]) would have stored. */
+#define FP8MI_EPILOGUE_TRANSPOSED 0x100
 
 /* scale layouts */
 enum { FP8MI_SCALE_TENSOR = 0, /* one float                               */
@@ -63,8 +75,9 @@ enum { FP8MI_KERNEL_AUTO = 0,
        FP8MI_KERNEL_GEMM_128x64 = 5, /* 128x64x128 tile (few tiles: one per CU)       */
        FP8MI_KERNEL_SKINNY = 6,    /* 1 <= M <= 64 weight-streaming MFMA              */
        FP8MI_KERNEL_GEMM_64x128 = 14 }; /* 64x128x128 tile (M <= 64, deep K)          */
-/* ids 7..13 select experimental schedule variants of the tile kernel (see
- * fp8mi_gemm.hip); they compute the same result and exist for A/B timing. */
+/* Other ids exist only in the diagnostic build of the library (libfp8mi_diag.so:
+ * schedule variants, the producer/consumer kernel and its ablations, kept for
+ * A/B timing - tools/README.md); the product library rejects them. */
 
 /* error codes (negative returns) */
 enum { FP8MI_OK = 0,
@@ -89,7 +102,7 @@ enum { FP8MI_OK = 0,
  * C        (M,N) out_dtype, row-major, leading dimension ldc >= N (elements)
  * scale_a  float[1] (FP8MI_SCALE_TENSOR) or float[M] (FP8MI_SCALE_ROW)
  * scale_b  float[1] or float[N]
- * bias     NULL or [N] of bias_dtype;  scale_result NULL or float[1]
+ * bias     NULL or [N] of bias_dtype ([M] with FP8MI_EPILOGUE_TRANSPOSED);  scale_result NULL or float[1]
  * Accumulation is float32.  M == 0 or N == 0 is a no-op; K == 0 writes the
  * epilogue of a zero sum.
  */
@@ -114,7 +127,7 @@ int fp8mi_scaled_mm_ex(const uint8_t *A, const uint8_t *B_nk, void *C,
                        int kernel, void *stream);
 
 /*
- * Split-K.  When M x N yields far fewer output tiles than the 256 CUs (small M,
+ * Split-K.  When M x N yields far fewer output tiles than the device has CUs (small M,
  * deep K: the decode / small-batch regime) the tile kernels can cut K into
  * `split_k` slices, one workgroup per (tile, slice); the slices' fp32 partial
  * tiles meet in `workspace`, and the last workgroup of a tile to finish adds
@@ -125,17 +138,26 @@ int fp8mi_scaled_mm_ex(const uint8_t *A, const uint8_t *B_nk, void *C,
  * workspace        device buffer, 16-byte aligned, used by ONE launch at a time
  *                  (launches on one stream may share it; concurrent streams
  *                  need their own).  Its first FP8MI_WS_COUNTER_BYTES bytes
- *                  must be zero before the first launch that uses it; every
- *                  launch leaves them zero.  NULL: never split.
+ *                  (the tiles' arrival counters) must be zero before the first
+ *                  launch that uses it - fp8mi_workspace_reset() - and every
+ *                  launch that completes leaves them zero.  A launch that is
+ *                  ABORTED mid-flight (device fault) can leave a counter
+ *                  non-zero, and later launches on that workspace would then
+ *                  mis-reduce silently: reset the workspace as part of any
+ *                  error recovery.  NULL: never split.
  * workspace_bytes  its size; fp8mi_scaled_mm_workspace_bytes() is enough for
  *                  every problem the library would split on its own.  A
  *                  workspace that is too small silently disables the split.
  * split_k          0: library decides; 1: no split; > 1: that many slices
- *                  (clamped to what K and the workspace allow).
+ *                  (clamped to the largest count K and the workspace allow).
  * fp8mi_scaled_mm / _ex are this call with workspace == NULL.
  */
 #define FP8MI_WS_COUNTER_BYTES 4096
 int64_t fp8mi_scaled_mm_workspace_bytes(void);
+/* Enqueue a memset of the counter block (FP8MI_WS_COUNTER_BYTES at the head of
+ * `workspace`) on `stream`: once after allocating a workspace, and after any
+ * aborted launch.  Graph-capturable (a memset node). */
+int fp8mi_workspace_reset(void *workspace, int64_t workspace_bytes, void *stream);
 int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C,
                        const float *scale_a, const float *scale_b,
                        const void *bias, const float *scale_result,

@@ -42,7 +42,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_argument_errors_without_gpu(lib):
-    assert lib.fp8mi_version() == 0x000200
+    assert lib.fp8mi_version() == 0x000300
     # argument validation happens before any HIP call, so it is testable here
     rc = lib.fp8mi_scaled_mm(None, None, None, None, None, None, None, 4, 4, 4, 4, 4, 4, 0, 0, 0, 0, 0, None)
     assert rc == -1 and b"NULL" in lib.fp8mi_last_error()
@@ -191,3 +191,44 @@ def test_scaled_mm_cpu_passthrough_and_positional_scales(patch):
         pytest.skip(f"torch-CPU _scaled_mm unavailable: {e}")
     assert torch.equal(torch._scaled_mm(a, b, scale_a=one, scale_b=one, out_dtype=torch.float32), ref)
     assert torch.equal(torch._scaled_mm(a, b, one, one, out_dtype=torch.float32), ref)
+
+
+def test_plugin_entry_installs_on_import_and_exports_empty_node_maps(capsys):
+    """The ComfyUI custom-node entry (reference __init__.py:13-61): importing the package directory's
+    __init__.py installs the patch as a side effect (:22-27), prints a banner, and exports empty node
+    mappings (:57-61).  ComfyUI loads custom nodes with importlib from the file path, so do the same."""
+    import importlib.util
+    import sys
+    import fp8_mps_patch as p
+    assert not p.is_installed()
+    o_mm, o_to, o_cp = torch._scaled_mm, torch.Tensor.to, torch.Tensor.copy_
+    spec = importlib.util.spec_from_file_location("fp8_mi355x_plugin_cpu_test", os.path.join(PKG, "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    try:
+        spec.loader.exec_module(mod)
+        assert p.is_installed() and torch._scaled_mm is p._metal_scaled_mm
+        assert mod.NODE_CLASS_MAPPINGS == {} and mod.NODE_DISPLAY_NAME_MAPPINGS == {}
+        assert sorted(mod.__all__) == ["NODE_CLASS_MAPPINGS", "NODE_DISPLAY_NAME_MAPPINGS"]
+        assert "patch installed" in capsys.readouterr().out
+        spec.loader.exec_module(mod)        # a second import leaves one installation (install() is idempotent)
+        assert p._original_scaled_mm is o_mm
+    finally:
+        p.uninstall()
+        sys.modules.pop(spec.name, None)
+    assert torch._scaled_mm is o_mm and torch.Tensor.to is o_to and torch.Tensor.copy_ is o_cp
+
+
+def test_plugin_entry_swallows_install_failure(monkeypatch, capsys):
+    """reference __init__.py:43-53: a failing install() is reported, not raised, so the host still starts."""
+    import importlib.util
+    import fp8_mps_patch as p
+
+    def boom():
+        raise RuntimeError("torch._scaled_mm not found")
+    monkeypatch.setattr(p, "install", boom)
+    spec = importlib.util.spec_from_file_location("fp8_mi355x_plugin_fail_test", os.path.join(PKG, "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert not p.is_installed() and mod.NODE_CLASS_MAPPINGS == {}
+    assert "WARNING" in capsys.readouterr().out

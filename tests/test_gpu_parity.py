@@ -33,6 +33,10 @@ REL_RMSE_GATE = 0.045  # reference reports 4.0 % (README.md:86), gates at 15 %
 
 import fp8_mi355x_lib as L  # noqa: E402
 
+# every LDS-tiled MFMA kernel of the product library (the schedule variants and the producer/consumer kernel live in the
+# diagnostic library only: tools/check_kernel.py checks those against the oracle)
+TILE_KERNELS = [L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256, L.KERNEL_GEMM_64x128]
+
 
 def dev(x, cuda, dtype=None):
     t = torch.from_numpy(np.ascontiguousarray(x))
@@ -48,7 +52,7 @@ def clean_bytes(rng, shape):
 
 
 def uses_mfma(kernel, M, K):
-    if kernel in (L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256, L.KERNEL_SKINNY) or kernel >= 7:
+    if kernel in TILE_KERNELS or kernel == L.KERNEL_SKINNY:
         return True
     return kernel == L.KERNEL_AUTO and M > 1 and K % 16 == 0 and K > 0
 
@@ -252,7 +256,7 @@ def _golden_cases(golden_dir):
 def _kernels_for(M, K):
     ks = [L.KERNEL_AUTO, L.KERNEL_GENERIC]
     if K % 16 == 0:
-        ks += [L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256]
+        ks += TILE_KERNELS
         if M == 1:
             ks.append(L.KERNEL_GEMV)
         if M <= 64:
@@ -312,7 +316,7 @@ def test_gemv_shapes(native, cuda, oracle, M, K, N):
     check_mm(oracle, native, cuda, x, W, [0.013], sw)  # auto dispatch picks the same path
 
 
-@pytest.mark.parametrize("kernel", [L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256])
+@pytest.mark.parametrize("kernel", TILE_KERNELS)
 @pytest.mark.parametrize("M,K,N", [(1, 128, 1), (5, 16, 3), (128, 128, 128), (130, 272, 70), (300, 1040, 200),
                                    (256, 512, 256), (257, 384, 513), (64, 4096, 96),
                                    (1300, 144, 900), (700, 32, 1100)])
@@ -362,7 +366,7 @@ def test_gemm_mfma_operand_map_asymmetric(native, cuda, oracle):
     assert np.array_equal(got.cpu().numpy(), exp)
 
 
-@pytest.mark.parametrize("kernel", [L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256])
+@pytest.mark.parametrize("kernel", TILE_KERNELS)
 def test_gemm_fp32_exact_on_narrow_range(native, cuda, oracle, kernel):
     """Operands with |x| in [0.25, 4): all products lie within 2^8 of each other,
     above the matrix core's alignment cut-off, so the MFMA kernels must agree
@@ -380,7 +384,7 @@ def test_gemm_full_size_c3_against_oracle(native, cuda, oracle):
     rng = np.random.default_rng(1234)
     A = clean_bytes(rng, (512, 4096))
     B = clean_bytes(rng, (4096, 4096))
-    for kernel in (L.KERNEL_AUTO, L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256):
+    for kernel in [L.KERNEL_AUTO] + TILE_KERNELS:
         check_mm(oracle, native, cuda, A, B, [0.01], [0.01], kernel=kernel)
 
 
@@ -447,12 +451,12 @@ def test_fused_epilogue(native, cuda, oracle, out_dtype, M):
     assert np.all(np.abs(got - exact) <= (MFMA_TOL if M > 1 else MM_TOL) * bound + 1e-30)
 
 
-@pytest.mark.parametrize("kernel", [L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256, 7, 8, 9, 10])
+@pytest.mark.parametrize("kernel", TILE_KERNELS)
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_full_tile_staged_epilogue(native, cuda, oracle, kernel, out_dtype):
     """Interior (full) tiles take the LDS-staged, line-coalesced epilogue: per-row
     scales, bias and result scale must land on the right rows / columns in every
-    tile variant and output type (ids >= 7 are the schedule variants kept for A/B timing)."""
+    tile variant and output type."""
     rng = np.random.default_rng(55)
     M, K, N = 512, 384, 768
     A = clean_bytes(rng, (M, K))

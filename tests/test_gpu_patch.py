@@ -192,13 +192,14 @@ def test_fp8_linear_dynamic_quant_chain(native, cuda, oracle):
 
 
 def test_sharded_linear_on_gpu_single_rank_group(native, cuda, oracle):
-    """The N-column-sharded linear through its collective branch (RCCL, side
-    stream, events) with a 1-rank group - all one GPU allows; world 2 runs
-    under gloo in tests/test_sharded_gloo.py."""
+    """The N-column-sharded linear through its collective branch (RCCL, side stream, events, in-place gather) with a
+    1-rank group - all one GPU allows; world 2 runs under gloo in tests/test_sharded_gloo.py.  The result must equal the
+    UNSHARDED fused call bit for bit, bf16 output and bias included (the transposed epilogue adds the bias before the
+    single cast and applies the scales in the untransposed order), and a captured HIP graph of the forward replays it."""
     import torch.distributed as dist
     from fp8_sharded_linear import ColumnShardedFP8Linear
     g = torch.Generator().manual_seed(3)
-    M, K, N = 96, 512, 256
+    M, K, N = 384, 1024, 512
     x = torch.randint(0, 120, (M, K), dtype=torch.uint8, generator=g).to(cuda)
     W = torch.randint(0, 120, (N, K), dtype=torch.uint8, generator=g).to(cuda)
     sb = (torch.rand(N, generator=g) * 0.01 + 0.005).to(cuda)
@@ -206,16 +207,76 @@ def test_sharded_linear_on_gpu_single_rank_group(native, cuda, oracle):
     sa = torch.tensor([0.02], device=cuda)
     exact = oracle.scaled_mm(x.cpu().numpy(), W.cpu().numpy(), [0.02], sb.cpu().numpy(), accumulate="f64") + bias.cpu().numpy()[None, :]
     bound = oracle.abs_dot_bound(x.cpu().numpy(), W.cpu().numpy(), [0.02], sb.cpu().numpy()) + bias.abs().cpu().numpy()[None, :]
-    lin = ColumnShardedFP8Linear.from_full(W, sb, bias, chunks=4, out_dtype=torch.float32)   # no group: plain copy
-    y0 = lin(x, sa)
-    assert y0.shape == (M, N) and np.all(np.abs(y0.cpu().numpy() - exact) <= 1e-3 * bound)
+    refs = {}
+    for od in (torch.float32, torch.bfloat16):
+        refs[od] = native.fp8_scaled_mm(x, W, sa, sb, bias=bias, out_dtype=od, split_k=1)     # unsharded, fused
+        eps = 2.0 ** -8 if od == torch.bfloat16 else 0.0
+        assert np.all(np.abs(refs[od].float().cpu().numpy() - exact) <= 1e-3 * bound + eps * np.abs(exact))
+        for chunks in (1, 4):
+            lin = ColumnShardedFP8Linear.from_full(W, sb, bias, chunks=chunks, out_dtype=od)   # no group: slots only
+            y0 = lin(x, sa)
+            assert y0.shape == (M, N) and y0.stride() == (1, M)
+            assert torch.equal(y0, refs[od]), (od, chunks)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda)
     try:
-        lin = ColumnShardedFP8Linear.from_full(W, sb, bias, chunks=4, out_dtype=torch.float32)
-        y1 = lin(x, sa)
+        for od in (torch.float32, torch.bfloat16):
+            lin = ColumnShardedFP8Linear.from_full(W, sb, bias, chunks=4, out_dtype=od)
+            y1 = lin(x, sa)
+            torch.cuda.synchronize()
+            assert torch.equal(y1, refs[od])
+            assert torch.equal(lin(x, sa), refs[od])           # second call: the module's stream / events are reused
+        # the forward as a HIP graph (side-stream fork / join inside the capture)
+        lin = ColumnShardedFP8Linear.from_full(W, sb, bias, chunks=2, out_dtype=torch.bfloat16)
+        lin(x, sa)
         torch.cuda.synchronize()
-        assert torch.equal(y1, y0)
+        side = torch.cuda.Stream(device=cuda)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                yg = lin(x, sa)
+        yg.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(yg, refs[torch.bfloat16])
     finally:
         dist.destroy_process_group()
+
+
+def test_transposed_epilogue_equals_untransposed_bits(native, cuda, oracle):
+    """FP8MI_EPILOGUE_TRANSPOSED: C^T = W . X^T with bias per ROW and the scales applied in the untransposed order gives
+    the transpose of the plain fused call bit for bit on every tile kernel (same K order in all of them), lands in a
+    caller-provided slab with a row stride, and stays within the oracle's bound on the other kernels."""
+    import fp8_mi355x_lib as L
+    rng = np.random.default_rng(8)
+    for (M, K, N) in ((256, 512, 384), (512, 3072, 256), (130, 272, 70)):
+        X = torch.from_numpy(rng.integers(0, 127, size=(M, K), dtype=np.uint8)).to(cuda)
+        W = torch.from_numpy(rng.integers(0, 127, size=(N, K), dtype=np.uint8)).to(cuda)
+        sx = torch.tensor([0.013], device=cuda)
+        sw = torch.from_numpy(rng.uniform(0.005, 0.02, size=N).astype(np.float32)).to(cuda)
+        b = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(cuda)
+        for od in (torch.float32, torch.bfloat16, torch.float16):
+            for kern in (L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256, L.KERNEL_GEMM_64x128):
+                plain = native.fp8_scaled_mm(X, W, sx, sw, bias=b, out_dtype=od, kernel=kern, split_k=1)
+                big = torch.full((N + 3, M + 16), 7.0, dtype=od, device=cuda)      # slab with a row stride
+                slot = big[2:2 + N, :M]
+                got = native.fp8_scaled_mm(W, X, sw, sx, bias=b, out_dtype=od, kernel=kern, split_k=1, out=slot,
+                                           transposed_epilogue=True)
+                assert got.data_ptr() == slot.data_ptr()
+                assert torch.equal(slot.t(), plain), (M, K, N, od, kern)
+                assert bool((big[:2] == 7).all()) and bool((big[2 + N:] == 7).all()) and bool((big[:, M:] == 7).all())
+    # every other kernel family: the same flag, checked against the oracle (their summation orders differ)
+    for (Mx, K, N, kern) in ((1, 512, 64, L.KERNEL_AUTO), (40, 1024, 1, L.KERNEL_AUTO), (40, 1024, 24, L.KERNEL_SKINNY),
+                             (9, 100, 7, L.KERNEL_GENERIC)):
+        X = rng.integers(0, 127, size=(Mx, K), dtype=np.uint8)
+        W = rng.integers(0, 127, size=(N, K), dtype=np.uint8)
+        sw = rng.uniform(0.005, 0.02, size=N).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32)
+        got = native.fp8_scaled_mm(torch.from_numpy(W).to(cuda), torch.from_numpy(X).to(cuda), torch.from_numpy(sw).to(cuda),
+                                   torch.tensor([0.013], device=cuda), bias=torch.from_numpy(b).to(cuda), kernel=kern,
+                                   transposed_epilogue=True)
+        exact = oracle.scaled_mm(X, W, [0.013], sw, accumulate="f64") + b[None, :]
+        bound = oracle.abs_dot_bound(X, W, [0.013], sw) + np.abs(b)[None, :]
+        assert got.shape == (N, Mx)
+        assert np.all(np.abs(got.cpu().numpy().T - exact) <= 1e-3 * bound + 1e-30), (Mx, K, N, kern)

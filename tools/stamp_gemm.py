@@ -33,3 +33,8 @@ print("  wave kWaves/2", " ".join(f"{x:8.0f}" for x in w4.mean(0)))
 tot = a[:, 5] + a[:, 6]
 print(f"in-kernel shader clock over the tile: {(tot / a[:, 7]).mean() * 0.1:.2f} GHz (min {(tot / a[:, 7]).min() * 0.1:.2f}, max {(tot / a[:, 7]).max() * 0.1:.2f}); tile wall {a[:, 7].mean() / 100:.1f} us")
 print(f"per tile (wave 0): entry->end of K loop {a[:, 5].mean():9.0f} ticks (loop body {a[:, :4].sum(1).mean():9.0f}), epilogue+store drain {a[:, 6].mean():9.0f} ticks")
+ph = full[:, 26:31]
+print("phases of wave 0, ticks (mean / min / max over blocks):")
+for name, v in (("entry -> prologue issue starts", ph[:, 0] - ph[:, 3]), ("prologue issue (first stages' DMA)", ph[:, 1] - ph[:, 0]),
+                ("K loop incl. final barrier", ph[:, 2] - ph[:, 1]), ("NaN vote / split-K", ph[:, 4] - ph[:, 2])):
+    print(f"  {name:36s} {v.mean():9.0f} {v.min():9.0f} {v.max():9.0f}")
