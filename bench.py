@@ -19,7 +19,13 @@ Workloads (BASELINE.json configs):
            N dimension is column-sharded over the ranks and the output is
            all-gathered over RCCL/xGMI ("strong" scaling: fixed total work)
   skinny   M=4, K=N=4096               (the reference's batch-4 shape, README.md:77; GB/s)
-  quantize / dequant   2^30 elements   (configs[4])
+  gemv_sq  M=1, K=N=14336              (the reference's published big GEMV shape, README.md:77-82)
+  quantize / quantize_rne / dequant   2^30 elements   (configs[4]; _rne = torch/OCP rounding through the hardware convert)
+
+Every step lasts >= 16 ms (as many passes over the rotating weight buffers as that takes), so the driver's 20 steps
+time >= 0.3 s of sustained work per workload.  `measured_ceilings` are probes run in the same process (tools/
+ceiling_probe.hip: register-only fp8 MFMA loop, streaming reads); `roofline.traffic` comes from the PMC passes of
+tools/profile_round.sh and is null unless profiles/pmc_traffic.json was measured on the kernel sources running now.
 
 Two objects ride on the line: `roofline` for the dominant kernel - algorithmic
 flops or bytes per launch / the kernel's average DEVICE duration, the latter
@@ -30,11 +36,19 @@ sample of the same workload.  The oracle is only ever the baseline / checker.
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import subprocess
 import sys
 import time
+
+# Kernel arguments in device memory instead of host memory: a runtime knob of the HIP runtime that must be set before
+# libamdhip64 loads (i.e. before `import torch`).  Measured on MI355X (profiles/r02_kernarg.txt): every launch of a
+# 5-20 us kernel is 1.2-1.7 us shorter (a scalar load from a host-memory kernarg segment is a PCIe round trip).  The
+# kernels also load all their arguments in one clause, so the setting is a deployment recommendation,
+# not a requirement; the line reports which way it ran (`config.dev_kernarg`).
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "fp8-mps-metal_amd")
@@ -91,8 +105,11 @@ def clean_bytes(shape, dev, gen):
 MAX_STREAMS = 4
 
 # name -> (M, K, N); "decode" = a small batch against the C2 weight shape (split-K fills the chip)
+# "gemv_sq" = the reference's one published big GEMV shape (test_fp8_metal.py:233-235, README.md:77-82: 2.38 ms on M4 Pro)
 MM_WORKLOADS = {"gemm": (512, 4096, 4096), "gemv": (1, 14336, 4096), "flux": (4096, 3072, 12288),
-                "skinny": (4, 4096, 4096), "decode": (64, 14336, 4096)}
+                "skinny": (4, 4096, 4096), "decode": (64, 14336, 4096), "gemv_sq": (1, 14336, 14336)}
+WEIGHT_STREAMING = ("gemv", "skinny", "decode", "gemv_sq")   # quoted in GB/s of algorithmic bytes
+TARGET_STEP_S = 0.016   # a step lasts >= 16 ms: the driver's 20 steps time >= 0.3 s of sustained work per workload
 
 
 class Workload:
@@ -119,12 +136,12 @@ class Workload:
             self.sb = torch.full((1,), 0.01, dtype=torch.float32, device=dev)
             self.flops = 2.0 * M * Nl * K
             self.bytes = float(M * K + Nl * K + esz * M * Nl)
-            self.unit_flops = name not in ("gemv", "skinny", "decode")   # weight-streaming shapes are quoted in GB/s
+            self.unit_flops = name not in WEIGHT_STREAMING
             # split-K workspaces (include/fp8mi.h): owned by the caller, counter block zeroed once; one per
             # concurrent launch chain (--streams)
             self.wss = [torch.zeros(int(self.lib.fp8mi_scaled_mm_workspace_bytes()), dtype=torch.uint8, device=dev)
                         for _ in range(MAX_STREAMS)]
-            self.inner = nbuf * (4 if name == "gemv" else 1)
+            self.inner = nbuf
             if self.sharded:
                 # the shipped N-column-sharded linear (fp8_sharded_linear.py): transposed blocks,
                 # chunk-cyclic rows, all-gather of chunk j on a side stream under the GEMM of chunk j+1
@@ -159,10 +176,11 @@ class Workload:
             self.inner = nbuf
             self.desc = {"workload": f"linear: x bf16 ({M},{K}) -> amax + encode -> scaled_mm with W e4m3fn ({N},{K}) -> bf16; "
                                      f"3 launches per linear, {nbuf} rotating weight buffers", "M": M, "K": K, "N": N}
-        elif name in ("quantize", "dequant"):
+        elif name in ("quantize", "quantize_rne", "dequant"):
             n = 1 << 30
             self.count = n
-            if name == "quantize":
+            self.enc_mode = L.ENC_RNE if name == "quantize_rne" else L.ENC_REFERENCE
+            if name != "dequant":
                 self.src = [torch.randn(n, device=dev, generator=gen) * 16 for _ in range(1)]
                 self.dst = [torch.empty(n, dtype=torch.uint8, device=dev)]
                 self.bytes = 5.0 * n
@@ -173,8 +191,9 @@ class Workload:
             self.flops = 0.0
             self.unit_flops = False
             self.inner = 2
-            self.desc = {"workload": f"{name}: 2^30 elements ({'fp32 -> e4m3fn' if name == 'quantize' else 'e4m3fn -> fp16'})",
-                         "elements": n}
+            what = {"quantize": "fp32 -> e4m3fn, reference rounding rules", "dequant": "e4m3fn -> fp16",
+                    "quantize_rne": "fp32 -> e4m3fn, torch / OCP round-to-nearest-even (hardware convert)"}[name]
+            self.desc = {"workload": f"{name}: 2^30 elements ({what})", "elements": n}
         else:
             raise ValueError(name)
 
@@ -202,9 +221,9 @@ class Workload:
                                         self.scales.data_ptr() + 4, self.sb.data_ptr(), None, None, self.M, self.N, self.K,
                                         self.K, self.K, self.N, 0, 0, L.BF16, 0, L.NAN_ZERO, self.kernel, 0,
                                         ws.data_ptr(), ws.numel(), stream)
-        elif self.name == "quantize":
+        elif self.name in ("quantize", "quantize_rne"):
             rc = lib.fp8mi_encode(self.src[0].data_ptr(), L.F32, self.dst[0].data_ptr(), None, self.count,
-                                  L.ENC_REFERENCE, stream)
+                                  self.enc_mode, stream)
         else:
             rc = lib.fp8mi_dequant(self.src[0].data_ptr(), self.dst[0].data_ptr(), None, self.count, L.F16, stream)
         L.check(rc, f"bench launch {self.name}")
@@ -235,13 +254,23 @@ def time_steps(w, steps, warmup, use_graph, world, n_streams=1):
     dev = w.dev
     graph = None
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 and not w.sharded else None
-    if w.name in ("quantize", "dequant", "linear"):
+    if w.name in ("quantize", "quantize_rne", "dequant", "linear"):
         streams = None  # these reuse one output buffer per launch
     if use_graph and world == 1 and not w.sharded:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             w.step(streams)  # warm every code path before capture
+            # size the step: enough launches that one step lasts >= TARGET_STEP_S (a whole number of passes over the
+            # rotating weight buffers), so the timed region is sustained work, not a 7 ms burst
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            w.step(streams)
+            e1.record(side)
+            e1.synchronize()
+            per_pass = max(e0.elapsed_time(e1) * 1e-3, 1e-6)
+            base = w.inner
+            w.inner = base * max(1, min(4096 // max(base, 1), int(TARGET_STEP_S / per_pass + 0.999)))
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
@@ -281,7 +310,88 @@ def kernel_durations(w, launches):
     return {"avg_s": sum(ms) / len(ms) * 1e-3, "min_s": ms[0] * 1e-3, "median_s": ms[len(ms) // 2] * 1e-3, "n": len(ms)}
 
 
-def roofline_of(w, kd, info, traffic):
+_PROBE = None
+
+
+def _probe_lib():
+    """tools/libceiling_probe.so (not part of the product): register-only fp8 MFMA loop + streaming-read kernel."""
+    global _PROBE
+    if _PROBE is None:
+        so = os.path.join(ROOT, "tools", "libceiling_probe.so")
+        src = os.path.join(ROOT, "tools", "ceiling_probe.hip")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", src, "-o", so])
+        lib = ctypes.CDLL(so)
+        vp = ctypes.c_void_p
+        lib.probe_mfma.restype = ctypes.c_int
+        lib.probe_mfma.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+        lib.probe_mfma_flops.restype = ctypes.c_double
+        lib.probe_mfma_flops.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        lib.probe_read.restype = ctypes.c_int
+        lib.probe_read.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_int, vp]
+        _PROBE = lib
+    return _PROBE
+
+
+def measure_ceilings(dev, info):
+    """What THIS device sustains, measured in this run (each >= 50 ms of work):
+      mfma_TFLOPs        fp8 MFMA (the GEMM's instruction) back to back from registers on weight-like bytes, every CU busy
+      read_large_GBs     streaming read of a 2 GiB buffer (cold: larger than the 256 MiB Infinity Cache)
+      read_56MiB_GBs     a 56 MiB buffer read once per launch, 6 rotating buffers (the size of config C2's weights):
+                         includes the launch ramp a 10 us kernel cannot amortise."""
+    try:
+        lib = _probe_lib()
+        st = torch.cuda.current_stream(dev)
+        gen = torch.Generator(device=dev).manual_seed(7)
+        ops = clean_bytes((32 * 1024,), dev, gen)
+        blocks, waves, iters = 2 * info["compute_units"], 8, 20000
+        out = torch.empty(blocks * waves * 64 * 4, dtype=torch.float32, device=dev)
+
+        def timed(fn, reps):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(reps):
+                fn()
+            e1.record(st)
+            e1.synchronize()
+            return e0.elapsed_time(e1) * 1e-3 / reps
+
+        t = timed(lambda: lib.probe_mfma(ops.data_ptr(), out.data_ptr(), blocks, waves, iters, st.cuda_stream), 12)
+        mfma = lib.probe_mfma_flops(blocks, waves, iters) / t / 1e12
+        sink = torch.zeros(1, dtype=torch.int32, device=dev)
+        big = torch.ones(2 << 30, dtype=torch.uint8, device=dev)
+        t = timed(lambda: lib.probe_read(big.data_ptr(), sink.data_ptr(), big.numel(), 4096, st.cuda_stream), 8)
+        read_large = big.numel() / t / 1e9
+        del big
+        n56 = 56 << 20
+        bufs = [torch.ones(n56, dtype=torch.uint8, device=dev) for _ in range(6)]
+        it = [0]
+
+        def rot():
+            lib.probe_read(bufs[it[0] % 6].data_ptr(), sink.data_ptr(), n56, 2048, st.cuda_stream)
+            it[0] += 1
+        t = timed(rot, 600)
+        read_small = n56 / t / 1e9
+        del bufs
+        torch.cuda.empty_cache()
+        return {"mfma_TFLOPs": round(mfma, 1), "read_large_GBs": round(read_large, 1), "read_56MiB_GBs": round(read_small, 1)}
+    except Exception as e:  # the ceilings are context; never let them take the bench line down
+        return {"error": repr(e)}
+
+
+def source_fingerprint():
+    """sha256 over the kernel sources: profiles/pmc_traffic.json is only valid for the kernels it was measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def roofline_of(w, kd, info, traffic, ceilings=None):
     if kd is None:
         return None
     if w.unit_flops:
@@ -295,9 +405,9 @@ def roofline_of(w, kd, info, traffic):
     if w.unit_flops:  # C3 sits at the ridge: also say how far the same launch is from the HBM roof
         r["hbm_achieved_GBs"] = round(w.bytes / kd["avg_s"] / 1e9, 1)
         r["hbm_frac"] = round(r["hbm_achieved_GBs"] / HBM_PEAK_GBS, 4)
-    # informational: what this part sustains in isolation (profiles/r01_peak_probe.txt):
-    # register-only fp8 MFMA loop on weight-like bytes; 4 GiB streaming read
-    r["measured_ceiling"] = 4200.0 if w.unit_flops else 5700.0
+    # informational: what this device sustained in isolation in THIS run (measure_ceilings)
+    c = ceilings or {}
+    r["measured_ceiling"] = c.get("mfma_TFLOPs") if w.unit_flops else c.get("read_large_GBs")
     r["traffic"] = traffic
     r["kernel_avg_us"] = round(kd["avg_s"] * 1e6, 3)
     r["kernel_min_us"] = round(kd["min_s"] * 1e6, 3)
@@ -340,6 +450,28 @@ def cpu_baseline(w, budget_s=12.0):
         else:
             val, unit = (N * K + K + 4 * N) * reps / tt / 1e9, "GB/s"
         sample = f"{reps} x fp8o_scaled_mm (oracle/fp8_oracle.c, OpenMP) on M={rows} of {w.M} rows, K={K}, N={N}; {tt:.1f} s"
+        # the torch-CPU variant of the same restatement - LUT decode of both operands + float32 matmul,
+        # every call (the reference's CPU path re-dequantises the weights per call), all host threads
+        try:
+            import fp8_oracle
+            torch.set_num_threads(os.cpu_count() or 1)
+            lut = torch.from_numpy(fp8_oracle.decode_lut())
+            At = torch.from_numpy(rng.integers(0, 127, size=(rows, K), dtype=np.uint8)).long()
+            Bt = torch.from_numpy(B).long()
+
+            def run_t():
+                t0 = time.perf_counter()
+                (lut[At] @ lut[Bt].t()) * 0.01 * 0.01
+                return time.perf_counter() - t0
+            run_t()
+            t1 = run_t()
+            reps_t = int(min(200, max(1, round(budget_s / 3 / max(t1, 1e-6)))))
+            tt_t = sum(run_t() for _ in range(reps_t))
+            v_t = (2.0 * rows * N * K * reps_t / tt_t / 1e12) if w.unit_flops else ((N * K + K + 4 * N) * reps_t / tt_t / 1e9)
+            torch_lut = {"value": float(f"{v_t:.4g}"), "unit": unit, "cores": torch.get_num_threads(),
+                         "sample": f"{reps_t} x (LUT[A] @ LUT[B].T) * sa * sb in torch float32 on the same shape; {tt_t:.1f} s"}
+        except Exception as e:
+            torch_lut = {"error": repr(e)}
     else:
         n = 1 << 26
         if w.name == "quantize":
@@ -361,13 +493,32 @@ def cpu_baseline(w, budget_s=12.0):
         tt = time.perf_counter() - t0
         val, unit = per * n * reps / tt / 1e9, "GB/s"
         sample = f"{reps} x 2^26 elements of the 2^30 (oracle/fp8_oracle.c, OpenMP); {tt:.1f} s"
-    return {"value": float(f"{val:.4g}"), "unit": unit, "cores": cores, "kind": "port", "sample": sample}
+    res = {"value": float(f"{val:.4g}"), "unit": unit, "cores": cores, "kind": "port", "sample": sample,
+           "host_cpu": _cpu_model(), "host_logical_cpus": os.cpu_count()}
+    if w.name in MM_WORKLOADS:
+        res["torch_lut"] = torch_lut
+    return res
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def load_traffic(name):
+    """HBM-side bytes per launch from the PMC passes (tools/profile_round.sh -> profiles/pmc_traffic.json), or None when
+    that file was measured on other kernel sources than the ones running now (it carries their fingerprint)."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        return json.load(open(p)).get(name)
+        d = json.load(open(p))
+        if d.get("source_sha") != source_fingerprint():
+            return None
+        return d.get("traffic", {}).get(name)
     except Exception:
         return None
 
@@ -399,7 +550,7 @@ def allgather_only(w, reps=10):
         return {"error": repr(e)}
 
 
-def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info, nbuf=None, sharded=False, n_streams=1):
+def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info, nbuf=None, sharded=False, n_streams=1, ceilings=None):
     w = Workload(name, dev, world, rank, kernel, nbuf, sharded)
     dt, graphed = time_steps(w, steps, warmup, True, world, n_streams)
     launches = steps * w.inner
@@ -410,7 +561,7 @@ def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info, nbuf=
     kd = kernel_durations(w, min(4 * w.inner, 256)) if name != "linear" else None   # the chain is three kernels
     res = {"value": round(value, 3), "unit": unit, "ms_per_step": round(dt / steps * 1e3, 5),
            "launches_per_step": w.inner, "hip_graph": graphed, "streams": n_streams, "config": w.desc,
-           "roofline": roofline_of(w, kd, info, load_traffic(name) if world == 1 and not w.sharded else None)}
+           "roofline": roofline_of(w, kd, info, load_traffic(name) if world == 1 and not w.sharded else None, ceilings)}
     if w.sharded and dist.is_initialized():
         res["allgather_only"] = allgather_only(w)   # GEMM-only rate is roofline.achieved, this is the collective
     if with_cpu:
@@ -425,7 +576,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="auto", choices=["auto", "gemm", "gemv", "flux", "skinny", "decode", "linear", "quantize", "dequant"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "gemm", "gemv", "gemv_sq", "flux", "skinny", "decode", "linear",
+                                                           "quantize", "quantize_rne", "dequant"])
     ap.add_argument("--kernel", type=int, default=L.KERNEL_AUTO, help="force an FP8MI_KERNEL_* id")
     ap.add_argument("--nbuf", type=int, default=None, help="override the number of rotating weight buffers "
                     "(1 = weights stay cache-resident; for sensitivity experiments only)")
@@ -435,6 +587,7 @@ def main():
                     help="issue the step's independent launches round-robin over this many streams "
                          "(parallel branches of the captured graph); 1 = one serial chain (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ceilings", action="store_true", help="skip the in-run MFMA / streaming-read ceiling probes")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearse the multi-GPU code path (sharded linear + RCCL all-gather) with a 1-rank group")
@@ -468,9 +621,10 @@ def main():
     if world > 1 and primary != "flux":
         raise SystemExit("multi-GPU runs shard the FLUX linear (configs[3]); use --workload flux or auto")
 
+    ceilings = measure_ceilings(dev, info) if (world == 1 and not args.force_sharded and not args.no_ceilings) else None
     res = measure(primary, dev, args.steps, args.warmup, world, rank, args.kernel,
                   with_cpu=(world == 1 and rank == 0 and not args.no_cpu_baseline and not args.force_sharded and primary != "linear"),
-                  info=info, nbuf=args.nbuf, sharded=args.force_sharded, n_streams=args.streams)
+                  info=info, nbuf=args.nbuf, sharded=args.force_sharded, n_streams=args.streams, ceilings=ceilings)
     same_workload_1gpu = None
     if world > 1:
         # the N = 1 bench line is C3 (BASELINE.json's single-GPU config); for a like-for-like strong-scaling
@@ -488,14 +642,17 @@ def main():
         "metric": METRIC, "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
         "scaling": "strong" if primary == "flux" else "weak", "vs_baseline": None,
-        "dtype": "fp8_e4m3fn (fp32 accumulate)" if (primary in MM_WORKLOADS or primary == "linear") else "u8",
+        # what the path computes in: e4m3fn products summed by the gfx950 fp8 matrix core into fp32 accumulators (its
+        # in-group alignment is not IEEE fp32 addition: DESIGN.md 2) / the fp32 VALU for M = 1; bytes for the casts
+        "dtype": "fp8_e4m3fn (fp8 MFMA into fp32 accumulators)" if (primary in MM_WORKLOADS or primary == "linear") else "u8",
         "data": {"gauss": "synthetic (seeded N(0,1) amax-quantised to e4m3fn; weights rotate through > 256 MiB)",
                  "uniform": "synthetic (seeded uniform e4m3 bytes, NaN patterns remapped; weights rotate through > 256 MiB)",
                  "zeros": "synthetic (all-zero bytes; clock upper bound, not a reportable number)"}[args.data],
         "config": dict(res["config"], launches_per_step=res["launches_per_step"], hip_graph=res["hip_graph"],
                        parallelism=("N-column-sharded x%d, 2 chunk-cyclic row chunks per rank, RCCL all-gather "
                                     "pipelined under the GEMM (fp8_sharded_linear.py)" % world) if world > 1 else "single GPU",
-                       device=info["name"], arch=info["arch"], compute_units=info["compute_units"]),
+                       device=info["name"], arch=info["arch"], compute_units=info["compute_units"],
+                       dev_kernarg=os.environ.get("HIP_FORCE_DEV_KERNARG", "0") == "1"),
         "roofline": res["roofline"],
     }
     if "allgather_only" in res:
@@ -504,13 +661,17 @@ def main():
         line["same_workload_on_one_gpu"] = same_workload_1gpu
     if "cpu_baseline" in res:
         line["cpu_baseline"] = res["cpu_baseline"]
+    if ceilings is not None:
+        line["measured_ceilings"] = ceilings
 
     if world == 1 and args.workload == "auto" and not args.no_secondary and not args.force_sharded:
         sec = {}
-        for name in ("gemv", "flux", "skinny", "decode", "linear", "quantize", "dequant"):
+        for name in ("gemv", "gemv_sq", "flux", "skinny", "decode", "linear", "quantize", "quantize_rne", "dequant"):
             try:
                 r = measure(name, dev, max(3, args.steps // 2), max(1, args.warmup // 2), 1, 0, L.KERNEL_AUTO,
-                            with_cpu=(name == "gemv" and not args.no_cpu_baseline), info=info)
+                            with_cpu=(name == "gemv" and not args.no_cpu_baseline), info=info, ceilings=ceilings)
+                if name == "gemv_sq":   # the reference's own number for this shape, on its own hardware (not a baseline for MI355X)
+                    r["reference_published"] = {"ms": 2.38, "hardware": "Apple M4 Pro", "source": "README.md:80 / test_fp8_metal.py:233-235"}
                 sec[name] = r
             except Exception as e:  # a secondary failure must not hide the primary number
                 sec[name] = {"error": repr(e)}

@@ -197,7 +197,7 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
 
     switch (kernel) {
     case FP8MI_KERNEL_AUTO:
-        if (fp8mi_gemv_supported(p)) return hip_result(fp8mi_launch_gemv(p, s), "gemv");
+        if (fp8mi_gemv_supported(p)) return hip_result(fp8mi_launch_gemv(p, false, s), "gemv");
         if (p.M >= 2 && p.M <= 48 && fp8mi_skinny_supported(p)) {
             // measured (tools/sweep_small_m.py): on small weight matrices the weight-streaming skinny kernel wins up
             // to M = 48 (K = N = 4096: 8.5-11.4 vs 11.4-12.6 us); on large ones (N*K >= 24 MiB) the split-K tile
@@ -216,7 +216,10 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
         return hip_result(fp8mi_launch_generic(p, s), "generic");
     case FP8MI_KERNEL_GEMV:
         if (!fp8mi_gemv_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "gemv kernel needs M == 1, K %% 16 == 0, 16-byte aligned rows");
-        return hip_result(fp8mi_launch_gemv(p, s), "gemv");
+        return hip_result(fp8mi_launch_gemv(p, false, s), "gemv");
+    case FP8MI_KERNEL_GEMV_FP32:
+        if (!fp8mi_gemv_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "gemv kernel needs M == 1, K %% 16 == 0, 16-byte aligned rows");
+        return hip_result(fp8mi_launch_gemv(p, true, s), "gemv-fp32");
     case FP8MI_KERNEL_SKINNY:
         if (!fp8mi_skinny_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "skinny kernel needs 1 <= M <= 64, K %% 16 == 0, 16-byte aligned rows");
         return hip_result(fp8mi_launch_skinny(p, s), "skinny");
@@ -229,6 +232,9 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     case FP8MI_KERNEL_GENERIC:
         return hip_result(fp8mi_launch_generic(p, s), "generic");
     default:
+#ifdef FP8MI_DIAG
+        if (kernel >= 40 && kernel <= 69 && fp8mi_gemv_supported(p)) return hip_result(fp8mi_launch_gemv_variant(p, kernel, s), "gemv-variant");
+#endif
 #ifdef FP8MI_DIAG  // diagnostic library only: schedule variants of the ring kernel (7..13, 30..37), the producer / consumer kernel
                    // (15..24) and its timing-only ablations (201..207)
         if (K > 0 && fp8mi_gemm_supported(p)) {

@@ -149,7 +149,8 @@ int fp8mi_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream_t s,
 int fp8mi_cu_count();
 
 // launchers implemented in the .hip files (host side, internal linkage by name)
-int fp8mi_launch_gemv(const MMParams &p, hipStream_t s);
+int fp8mi_launch_gemv(const MMParams &p, bool fp32_only, hipStream_t s);
+int fp8mi_launch_gemv_variant(const MMParams &p, int id, hipStream_t s);  // diagnostic library only
 bool fp8mi_gemv_supported(const MMParams &p);
 int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s);
 bool fp8mi_gemm_supported(const MMParams &p);

@@ -12,10 +12,14 @@
 //     (RB x STEPS dwordx4 per lane, compile-time unrolled), so the whole
 //     matrix is in flight within the first microsecond of the launch - at
 //     M == 1 the kernel lasts ~10 us and is latency-, not issue-, bound;
-//   * x is decoded ONCE per workgroup into registers (v_cvt_pk_f32_fp8), not
-//     once per row; W bytes are decoded with the same instruction and
-//     accumulated with packed fp32 FMAs (every e4m3 x e4m3 product is exact in
-//     fp32, so only the summation rounds);
+//   * x is loaded FIRST (loads return in issue order: behind the W slab it would arrive last and push every multiply-add
+//     into the kernel's tail) and handled once per workgroup, not once per row;
+//   * the multiply-add has two forms.  fp32: x and W decoded with v_cvt_pk_f32_fp8 and accumulated with packed fp32 FMAs
+//     (every e4m3 x e4m3 product is exact in fp32, so only the summation rounds) - 16 VALU instructions per KiB of W,
+//     which showed as ~1 us of config C2 even when overlapped.  MFMA (K > 4096): the matrix core takes the raw bytes of a
+//     lane as one operand and the x bytes of the same lane as the other; the DIAGONAL of the 16x16 product tile is the
+//     lane-wise dot product, its trace the wave's - no decode or FMA instructions at all (see the kernel body);
+//     accumulation is the fp8 matrix core's, as in the GEMM;
 //   * K is reduced across lanes by a wave64 butterfly, across the four waves
 //     through LDS; the scale / bias / result-scale / cast epilogue is fused.
 //
@@ -39,7 +43,7 @@ FP8MI_DEVICE void decode16(const u32x4 &w, f32x2 (&f)[8])
     }
 }
 
-template <int STEPS, int RB, bool NT = true, int kWaves = 4>
+template <int STEPS, int RB, bool NT = true, int kWaves = 4, int ABL = 0, bool MFMA = false>
 __global__ __launch_bounds__(kWaves * 64) void gemv_kernel(MMParams p_in)
 {
     const MMParams p = pin_params(p_in);  // every kernel argument in one scalar-load clause (fp8mi_common.h)
@@ -60,8 +64,12 @@ __global__ __launch_bounds__(kWaves * 64) void gemv_kernel(MMParams p_in)
     const uint8_t *__restrict__ W = p.B;
 
     f32x2 acc[RB];
+    [[maybe_unused]] f32x4 macc[RB];  // MFMA form: 16x16 product tiles whose DIAGONALS are the wanted dot products (see below)
 #pragma unroll
-    for (int r = 0; r < RB; ++r) acc[r] = f32x2{0.0f, 0.0f};
+    for (int r = 0; r < RB; ++r) {
+        acc[r] = f32x2{0.0f, 0.0f};
+        if constexpr (MFMA) macc[r] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
 
     // chunk of K handled per outer iteration: 4 waves x STEPS wave-steps of 1 KiB
     constexpr int64_t kChunk = (int64_t)kWaves * STEPS * 1024;
@@ -73,7 +81,16 @@ __global__ __launch_bounds__(kWaves * 64) void gemv_kernel(MMParams p_in)
             kb[i] = kc + (int64_t)(wave + kWaves * i) * 1024 + lane * 16;
             kv[i] = kb[i] < K;  // K % 16 == 0: a 16-byte piece is all in or all out
         }
-        // 1. issue every W load of this chunk
+        // 1. x for these k positions FIRST: loads return in issue order (vmcnt), so x behind the W slab would only arrive after
+        //    the last W byte and every multiply-add would sit in the kernel's tail (measured: 2.5-3.5 us of 14.4 on config C2);
+        //    x is 14 KiB from L2 and lands while the W loads are still being issued
+        u32x4 xr[STEPS];
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            xr[i] = u32x4{0u, 0u, 0u, 0u};
+            if (kv[i]) xr[i] = *(const u32x4 *)(x + kb[i]);
+        }
+        // 2. issue every W load of this chunk
         u32x4 w[RB][STEPS];
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
@@ -85,28 +102,64 @@ __global__ __launch_bounds__(kWaves * 64) void gemv_kernel(MMParams p_in)
                 else w[r][i] = u32x4{0u, 0u, 0u, 0u};
             }
         }
-        // 2. x for the same k positions, decoded once for all RB rows
-        f32x2 xs[STEPS][8];
+        if (p.nan_zero) {  // the reference's NaN rule for x (fp8_matmul.metal:21), once per workgroup
 #pragma unroll
-        for (int i = 0; i < STEPS; ++i) {
-            u32x4 xv = u32x4{0u, 0u, 0u, 0u};
-            if (kv[i]) xv = *(const u32x4 *)(x + kb[i]);
-            if (p.nan_zero) {
+            for (int i = 0; i < STEPS; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xv[j] = scrub_nan4(xv[j]);
-            }
-            decode16(xv, xs[i]);
+                for (int j = 0; j < 4; ++j) xr[i][j] = scrub_nan4(xr[i][j]);
         }
-        // 3. consume in issue order
+        if constexpr (MFMA) {
+            // 3m. the matrix core does the decode AND the multiply-add: v_mfma_scale_f32_16x16x128_f8f6f4 pairs byte j of
+            //     lane (i, g) of its first operand with byte j of lane (i', g) of its second for every (i, i'); with the W bytes
+            //     of a lane in the first operand and the x bytes of THE SAME lane (same k positions) in the second, the diagonal
+            //     D[i][i] = sum over the four lanes i, i+16, i+32, i+48 of their 32-byte dot products - and the trace is the dot
+            //     product over the 2 KiB the wave holds.  15/16 of the products are discarded, which the matrix pipe (4 % busy
+            //     here) does not notice; what is gone is the VALU work: 16 instructions per KiB (8 v_cvt_pk_f32_fp8 + 8
+            //     v_pk_fma_f32), measured 2.5-3.5 us of the 14.4 us of config C2 (timing-only build without the arithmetic:
+            //     10.9-11.9 us, profiles/r02_gemv_shapes.txt).
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+#pragma unroll
+                for (int i = 0; i < STEPS; i += 2) {
+                    const u32x4 w1 = i + 1 < STEPS ? w[r][i + 1] : u32x4{0u, 0u, 0u, 0u};
+                    const u32x4 x1 = i + 1 < STEPS ? xr[i + 1] : u32x4{0u, 0u, 0u, 0u};
+                    const i32x8 a = {(int)w[r][i][0], (int)w[r][i][1], (int)w[r][i][2], (int)w[r][i][3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+                    const i32x8 b = {(int)xr[i][0], (int)xr[i][1], (int)xr[i][2], (int)xr[i][3], (int)x1[0], (int)x1[1], (int)x1[2], (int)x1[3]};
+                    macc[r] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, macc[r], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                }
+            }
+        } else {
+            // 3. x decoded once for all RB rows (under the W stream)
+            f32x2 xs[STEPS][8];
+#pragma unroll
+            for (int i = 0; i < STEPS; ++i) decode16(xr[i], xs[i]);
+            // 4. consume in issue order
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+#pragma unroll
+                for (int i = 0; i < STEPS; ++i) {
+                    if constexpr (ABL == 1) {  // timing-only (diagnostic library): no decode, no FMA - the load structure alone
+                        acc[r][0] += __uint_as_float((w[r][i][0] ^ w[r][i][1] ^ w[r][i][2] ^ w[r][i][3]) & 0x3FFFFFFFu);
+                        continue;
+                    }
+                    f32x2 wf[8];
+                    decode16(w[r][i], wf);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[r] = xs[i][j] * wf[j] + acc[r];
+                }
+            }
+        }
+    }
+
+    if constexpr (MFMA) {
+        // the diagonal of each 16x16 tile: element (row 4 (lane >> 4) + j, column lane & 15) is held by this lane's j-th
+        // register, so the lanes with (lane & 15) >> 2 == lane >> 4 hold one diagonal element each (j = lane & 3)
+        const int fr = lane & 15, fg = lane >> 4;
+        const bool on_diag = (fr >> 2) == fg;
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-#pragma unroll
-            for (int i = 0; i < STEPS; ++i) {
-                f32x2 wf[8];
-                decode16(w[r][i], wf);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[r] = xs[i][j] * wf[j] + acc[r];
-            }
+            const float d = (fr & 2) ? ((fr & 1) ? macc[r][3] : macc[r][2]) : ((fr & 1) ? macc[r][1] : macc[r][0]);
+            acc[r] = f32x2{on_diag ? d : 0.0f, 0.0f};
         }
     }
 
@@ -159,11 +212,11 @@ __global__ __launch_bounds__(kWaves * 64) void gemv_kernel(MMParams p_in)
     }
 }
 
-template <int STEPS, int RB, bool NT = true, int kWaves = 4>
+template <int STEPS, int RB, bool NT = true, int kWaves = 4, int ABL = 0, bool MFMA = false>
 int launch(const MMParams &p, hipStream_t s)
 {
     const int64_t grid = (p.N + RB - 1) / RB;
-    return fp8mi_launch(gemv_kernel<STEPS, RB, NT, kWaves>, dim3((unsigned)grid), dim3(kWaves * 64), s, p);
+    return fp8mi_launch(gemv_kernel<STEPS, RB, NT, kWaves, ABL, MFMA>, dim3((unsigned)grid), dim3(kWaves * 64), s, p);
 }
 
 }  // namespace
@@ -174,17 +227,57 @@ bool fp8mi_gemv_supported(const MMParams &p)
            (((uintptr_t)p.B) & 15u) == 0 && (p.N + 3) / 4 <= 0x7FFFFFFF;
 }
 
-int fp8mi_launch_gemv(const MMParams &p, hipStream_t s)
+#ifdef FP8MI_DIAG  // launch-shape variants for A/B timing (diagnostic library only): <K-steps per wave, rows per workgroup, nt, waves>
+int fp8mi_launch_gemv_variant(const MMParams &p, int id, hipStream_t s)
+{
+    switch (id) {
+    case 40: return launch<4, 8>(p, s);               // the product's shape for C2
+    case 41: return launch<4, 4>(p, s);
+    case 42: return launch<2, 8, true, 8>(p, s);
+    case 43: return launch<2, 4, true, 8>(p, s);
+    case 44: return launch<4, 8, false>(p, s);        // default cache policy instead of nt
+    case 45: return launch<2, 2, true, 8>(p, s);
+    case 46: return launch<4, 2>(p, s);
+    case 47: return launch<1, 8, true, 16>(p, s);     // 16 waves x 1 KiB, 8 rows
+    case 48: return launch<2, 4, true, 8, 1>(p, s);   // <2,4,8 waves> with the arithmetic removed (timing only)
+    case 49: return launch<4, 8, true, 4, 1>(p, s);   // the product's shape with the arithmetic removed (timing only)
+    case 50: return launch<4, 8, true, 4, 0, true>(p, s);   // MFMA accumulate, <4,8>
+    case 51: return launch<2, 4, true, 8, 0, true>(p, s);   // MFMA accumulate, 8 waves x 2 steps, 4 rows
+    case 52: return launch<4, 4, true, 4, 0, true>(p, s);   // MFMA accumulate, <4,4>
+    case 53: return launch<2, 8, true, 8, 0, true>(p, s);   // MFMA accumulate, 8 waves x 2 steps, 8 rows
+    case 54: return launch<4, 2, true, 4, 0, true>(p, s);
+    case 55: return launch<2, 2, true, 8, 0, true>(p, s);
+    case 56: return launch<2, 4, true, 4, 0, true>(p, s);   // K <= 8192
+    case 57: return launch<2, 8, true, 4, 0, true>(p, s);
+    case 58: return launch<1, 4, true, 4, 0, true>(p, s);   // K <= 4096
+    case 59: return launch<1, 2, true, 4, 0, true>(p, s);
+    case 60: return launch<1, 8, true, 4, 0, true>(p, s);
+    case 61: return launch<1, 2>(p, s);
+    case 62: return launch<2, 2, true, 4, 0, true>(p, s);
+    case 63: return launch<4, 1, true, 4, 0, true>(p, s);
+    case 64: return launch<1, 1, true, 4, 0, true>(p, s);
+    default: return FP8MI_E_ENUM;
+    }
+}
+#endif
+
+int fp8mi_launch_gemv(const MMParams &p, bool fp32_only, hipStream_t s)
 {
     // wave-steps per wave for one pass over K (4 waves x 1 KiB per step)
     const int64_t steps = (p.K + 4095) / 4096;
-    // rows per workgroup: few rows = many small workgroups, which is what a 5-15 us kernel wants (measured with
-    // tools/time_shape.py; RB = 16 -> 4 at K = 4096: N = 14336 16.3 -> 12.2 us, N = 4096 8.4 -> 5.9 us; K = 8192: 15.8
-    // -> 15.0 us); with four wave-steps per wave (K > 8192) 8 rows are better until the grid gets short of ~450
-    // workgroups (K = 14336, N = 4096: 14.5 vs 15.5 us; K = 12288, N = 3072: 11.8 vs 10.4 us)
+    // Launch shape and arithmetic, measured on MI355X with x loaded ahead of the W slab (tools/ab_kernels.py on the
+    // diagnostic library, profiles/r02_gemv_shapes.txt).  Few rows per workgroup = many light workgroups, which is what a
+    // 5-30 us streaming kernel wants; past one wave-step per wave the matrix core takes over the multiply-add:
+    //   K <= 4096:  fp32 FMA, 4 rows   (K = N = 4096: 5.2-5.5 us for either form; N = 14336: 11.0 vs 12.5 us MFMA)
+    //   K <= 8192:  MFMA, 2 rows       (K = N = 8192: 11.5 vs 12.9 us fp32)
+    //   K  > 8192:  MFMA, 2 rows       (C2 K = 14336, N = 4096: 10.95 vs 12.0 us fp32 <4,2>, 13.2 us fp32 <4,8>; N = 14336: 30.7 vs 34.1 us)
+    // fp32_only (FP8MI_KERNEL_GEMV_FP32) keeps IEEE fp32 accumulation at every K.
     if (steps <= 1) return launch<1, 4>(p, s);
-    if (steps <= 2) return launch<2, 4>(p, s);
-    if ((p.N + 7) / 8 < (7 * (int64_t)fp8mi_cu_count()) / 4) return launch<4, 4>(p, s);
-    if (p.K > 16384) return launch<2, 4, true, 8>(p, s);  // 8 waves x 2 steps, loops over 16-KiB chunks (K = 28672, N = 8192: 41 vs 44.6 us)
-    return launch<4, 8>(p, s);
+    if (fp32_only) {
+        if (steps <= 2) return launch<2, 4>(p, s);
+        if (p.K > 16384) return launch<2, 4, true, 8>(p, s);  // 8 waves x 2 steps, loops over 16-KiB chunks
+        return launch<4, 2>(p, s);
+    }
+    if (steps <= 2) return launch<2, 2, true, 4, 0, true>(p, s);
+    return launch<4, 2, true, 4, 0, true>(p, s);
 }

@@ -54,6 +54,8 @@ def clean_bytes(rng, shape):
 def uses_mfma(kernel, M, K):
     if kernel in TILE_KERNELS or kernel == L.KERNEL_SKINNY:
         return True
+    if M == 1 and kernel in (L.KERNEL_AUTO, L.KERNEL_GEMV):
+        return K % 16 == 0 and K > 4096   # the vec-mat hands deep K to the matrix core; K <= 4096 (config C1) stays fp32 FMA
     return kernel == L.KERNEL_AUTO and M > 1 and K % 16 == 0 and K > 0
 
 
@@ -186,6 +188,26 @@ def test_encode_rne_mode_equals_torch_cpu(native, cuda, golden_dir):
     got = native.fp8_encode(x.to(cuda), encode_mode=L.ENC_RNE).cpu()
     assert torch.equal(got[:-2], exp[:-2])
     assert (got[-2:] & 0x7F).tolist() == [0x7F, 0x7F]
+    # the vector kernel runs the hardware convert (v_cvt_pk_fp8_f32) with explicit edges, the scalar kernel (misaligned
+    # views) the all-integer form: both must give torch-CPU's bytes, for every source dtype (test_mps_vs_cpu.py:283-357)
+    xd = x[:-2].to(cuda)
+    assert torch.equal(native.fp8_encode(xd[1:], encode_mode=L.ENC_RNE).cpu(), exp[1:-2])
+    edges = torch.tensor([2.0 ** -10, -(2.0 ** -10), 2.0 ** -10 * (1 + 2.0 ** -23), 2.0 ** -9 * 0.75, 2.0 ** -9, 1.5 * 2.0 ** -9,
+                          448.0, 463.99997, 464.0, 464.00003, -464.00003, 480.0, 1e30, float("inf"), -float("inf"), 0.0, -0.0,
+                          1.9375, 0.0146484375, 2.0 ** -6 * (1 - 2.0 ** -5)] * 16)
+    assert torch.equal(native.fp8_encode(edges.to(cuda), encode_mode=L.ENC_RNE).cpu(), edges.to(torch.float8_e4m3fn).view(torch.uint8))
+    for dt in (torch.float16, torch.bfloat16):
+        xs = x[:-2].to(dt)
+        xs = xs[torch.isfinite(xs)]
+        e2 = xs.to(torch.float8_e4m3fn).view(torch.uint8)
+        assert torch.equal(native.fp8_encode(xs.to(cuda), encode_mode=L.ENC_RNE).cpu(), e2), dt
+        assert torch.equal(native.fp8_encode(xs.to(cuda)[3:], encode_mode=L.ENC_RNE).cpu(), e2[3:]), dt
+    # amax-scaled quantisation in this mode: bytes = torch-CPU cast of x * float32(448 / amax)
+    g = torch.Generator().manual_seed(4)
+    y = torch.randn(70001, generator=g) * 5
+    q, inv = native.fp8_quantize(y.to(cuda), encode_mode=L.ENC_RNE)
+    scale = np.float32(448.0 / float(y.abs().max()))
+    assert torch.equal(q.cpu(), (y * float(scale)).to(torch.float8_e4m3fn).view(torch.uint8))
 
 
 def test_encode_other_dtypes_and_shapes(native, cuda, oracle):
@@ -258,7 +280,7 @@ def _kernels_for(M, K):
     if K % 16 == 0:
         ks += TILE_KERNELS
         if M == 1:
-            ks.append(L.KERNEL_GEMV)
+            ks += [L.KERNEL_GEMV, L.KERNEL_GEMV_FP32]
         if M <= 64:
             ks.append(L.KERNEL_SKINNY)
     return ks
@@ -314,6 +336,37 @@ def test_gemv_shapes(native, cuda, oracle, M, K, N):
     sw = rng.uniform(0.005, 0.02, size=N).astype(np.float32)
     check_mm(oracle, native, cuda, x, W, [0.013], sw, kernel=L.KERNEL_GEMV)
     check_mm(oracle, native, cuda, x, W, [0.013], sw)  # auto dispatch picks the same path
+    # the IEEE-fp32 form of the vec-mat (the reference's accumulation, fp8_matmul.metal:177-199) at every K
+    check_mm(oracle, native, cuda, x, W, [0.013], sw, kernel=L.KERNEL_GEMV_FP32, tol=MM_TOL)
+
+
+def test_gemv_matrix_core_form_is_exact_on_narrow_range(native, cuda, oracle):
+    """Deep-K vec-mat on the matrix core (diagonal of the 16x16 product tile): the hardware tolerance must not hide a
+    software error - operands within a 2^12 product range are summed exactly, so the result meets the fp32 bound; NaN
+    bytes in W / x follow both NaN modes; bias / per-row scale / bf16 epilogue as everywhere."""
+    rng = np.random.default_rng(77)
+    for (K, N) in ((6144, 300), (14336, 129), (20480, 33)):
+        x = (0x28 + rng.integers(0, 0x20, size=(1, K))).astype(np.uint8)
+        W = (0x28 + rng.integers(0, 0x20, size=(N, K))).astype(np.uint8)
+        check_mm(oracle, native, cuda, x, W, [0.5], [2.0], kernel=L.KERNEL_GEMV, tol=MM_TOL)
+        a = native.fp8_scaled_mm(dev(x, cuda), dev(W, cuda), torch.ones(1), torch.ones(1), kernel=L.KERNEL_GEMV)
+        b = native.fp8_scaled_mm(dev(x, cuda), dev(W, cuda), torch.ones(1), torch.ones(1), kernel=L.KERNEL_GEMV_FP32)
+        assert bool(((a - b).abs() <= MM_TOL * a.abs()).all())
+    x = clean_bytes(rng, (1, 8192))
+    W = clean_bytes(rng, (70, 8192))
+    W[7, 5] = 0x7F
+    W[9, 8191] = 0xFF
+    sw = rng.uniform(0.005, 0.02, size=70).astype(np.float32)
+    bias = rng.standard_normal(70).astype(np.float32)
+    check_mm(oracle, native, cuda, x, W, [0.5], sw, kernel=L.KERNEL_GEMV, bias=bias, scale_result=0.25, out_dtype=torch.bfloat16)
+    got = native.fp8_scaled_mm(dev(x, cuda), dev(W, cuda), torch.ones(1), torch.ones(1), kernel=L.KERNEL_GEMV,
+                               nan_mode=L.NAN_PROPAGATE).cpu().numpy()
+    assert np.isnan(got[0, 7]) and np.isnan(got[0, 9]) and np.isnan(got).sum() == 2    # OCP: only the rows holding NaN bytes
+    x[0, 4099] = 0xFF
+    check_mm(oracle, native, cuda, x, W, [0.5], sw, kernel=L.KERNEL_GEMV)               # reference: NaN byte = 0.0
+    got = native.fp8_scaled_mm(dev(x, cuda), dev(W, cuda), torch.ones(1), torch.ones(1), kernel=L.KERNEL_GEMV,
+                               nan_mode=L.NAN_PROPAGATE).cpu().numpy()
+    assert np.isnan(got).all()  # a NaN in x poisons every output
 
 
 @pytest.mark.parametrize("kernel", TILE_KERNELS)

@@ -1,30 +1,32 @@
 #!/bin/bash
 # Round profile on the GPU box: kernel trace of the default bench + HBM traffic counters per workload.
 #   tools/profile_round.sh <tag>        (writes gpurun_out/prof_<tag>/...)
-set -o pipefail
+set -uo pipefail
 tag=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$tag; rm -rf $O; mkdir -p $O; cd $R
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python bench.py --steps 10 --warmup 3 > $O/bench_under_rocprof.json 2> $O/kt.err || { echo "kernel-trace run failed"; tail -5 $O/kt.err; exit 1; }
-python tools/summarize_prof.py $O/kt > $O/kernel_trace_summary.txt
-for w in gemm gemv flux skinny decode quantize dequant; do
-  n=6; [ $w = quantize ] && n=3; [ $w = dequant ] && n=3
-  timeout -k 10 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_$w -o p -- python tools/run_workload.py $w $n > /dev/null 2>&1 || { echo "FETCH pass failed for $w"; exit 1; }
-  timeout -k 10 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_$w -o p -- python tools/run_workload.py $w $n > /dev/null 2>&1 || { echo "WRITE pass failed for $w"; exit 1; }
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun exports it)}; O="$R/gpurun_out/prof_$tag"; rm -rf "$O"; mkdir -p "$O"; cd "$R"
+export HIP_FORCE_DEV_KERNARG=1   # what bench.py runs with
+timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -o kt -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/kt.err" || { echo "kernel-trace run failed"; tail -5 $O/kt.err; exit 1; }
+python tools/summarize_prof.py "$O/kt" > "$O/kernel_trace_summary.txt"
+for w in gemm gemv gemv_sq flux skinny decode quantize quantize_rne dequant; do
+  n=6; [ $w = quantize ] && n=3; [ $w = quantize_rne ] && n=3; [ $w = dequant ] && n=3
+  timeout -k 10 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/fetch_$w" -o p -- python tools/run_workload.py $w $n > /dev/null 2>&1 || { echo "FETCH pass failed for $w"; exit 1; }
+  timeout -k 10 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write_$w" -o p -- python tools/run_workload.py $w $n > /dev/null 2>&1 || { echo "WRITE pass failed for $w"; exit 1; }
 done
 python - <<PY
 import csv, glob, json, os, collections
 O = "$O"
 out = {}; lines = []
-for w in ("gemm", "gemv", "flux", "skinny", "decode", "quantize", "dequant"):
+for w in ("gemm", "gemv", "gemv_sq", "flux", "skinny", "decode", "quantize", "quantize_rne", "dequant"):
     vals = {}
     for kind in ("fetch", "write"):
         f = glob.glob(os.path.join(O, f"{kind}_{w}", "**", "*counter_collection.csv"), recursive=True)[0]
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             # the workload's own kernel only (the synthetic-data generator also runs amax / encode kernels)
-            want = {"gemm": "gemm_kernel", "flux": "gemm_kernel", "decode": "gemm_kernel", "gemv": "gemv_kernel",
-                    "skinny": "skinny_kernel", "quantize": "encode_kernel<0, 0, false>", "dequant": "dequant_kernel"}[w]
+            want = {"gemm": "gemm_kernel", "flux": "gemm_kernel", "decode": "gemm_kernel", "gemv": "gemv_kernel", "gemv_sq": "gemv_kernel",
+                    "skinny": "skinny_kernel", "quantize": "encode_kernel<0, 0, false>", "quantize_rne": "encode_kernel<0, 1, false>",
+                    "dequant": "dequant_kernel"}[w]
             if want in r["Kernel_Name"]:
                 agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
         k, v = max(agg.items(), key=lambda kv: len(kv[1]))
@@ -35,8 +37,11 @@ for w in ("gemm", "gemv", "flux", "skinny", "decode", "quantize", "dequant"):
     traffic = int((2 * fetch_kb + write_kb) * 1024)
     out[w] = traffic
     lines.append(f"{w:9s} FETCH_SIZE {fetch_kb:12.1f} KiB (x2 gfx950 correction)  WRITE_SIZE {write_kb:12.1f} KiB  -> traffic/launch {traffic:14d} B   [{vals['fetch'][1][:70]}]")
-json.dump(out, open(os.path.join(O, "pmc_traffic.json"), "w"), indent=1)
+import sys
+sys.path.insert(0, "$R")
+import bench   # the fingerprint of the kernel sources these numbers belong to (bench.py prints traffic only when it matches)
+json.dump({"source_sha": bench.source_fingerprint(), "traffic": out}, open(os.path.join(O, "pmc_traffic.json"), "w"), indent=1)
 open(os.path.join(O, "pmc_traffic_summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 PY
-cat $O/kernel_trace_summary.txt | head -14
+head -20 "$O/kernel_trace_summary.txt"
