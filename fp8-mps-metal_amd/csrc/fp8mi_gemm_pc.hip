@@ -388,6 +388,11 @@ int fp8mi_launch_gemm_pc(const MMParams &p, int variant, hipStream_t s)
     case 21: return launch_pc<128, 128, 4, 2, 4, 4, 1>(p, s);    // 8 consumers (32x64) + 4 loaders
     case 22: return launch_pc<128, 64, 2, 2, 2, 3, 2>(p, s);     // 4 consumers + 2 loaders
     case 24: return launch_pc<128, 64, 2, 2, 4, 6, 1>(p, s);     // one K-step per stage, 6 x 24 KiB
+    case 25: return launch_pc<128, 64, 2, 2, 8, 3, 2>(p, s);     // 4 consumers + 8 loaders (two per SIMD)
+    case 26: return launch_pc<128, 64, 4, 2, 8, 3, 2>(p, s);     // 8 consumers + 8 loaders
+    case 27: return launch_pc<128, 128, 2, 2, 8, 4, 1>(p, s);    // 128x128, 4 consumers + 8 loaders
+    case 28: return launch_pc<128, 64, 2, 2, 8, 6, 1>(p, s);     // 8 loaders, one K-step per stage
+    case 208: return launch_pc<128, 64, 2, 2, 8, 3, 2, 3>(p, s); // LDS-DMA only, 8 loaders (timing only)
     // timing-only ablations of the 128x64 kernel (results are garbage): 20x, x = ablation bits
     case 201: return launch_pc<128, 64, 2, 2, 4, 3, 2, 1>(p, s);   // no ds_read
     case 202: return launch_pc<128, 64, 2, 2, 4, 3, 2, 2>(p, s);   // no MFMA

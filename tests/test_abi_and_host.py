@@ -232,3 +232,11 @@ def test_plugin_entry_swallows_install_failure(monkeypatch, capsys):
     spec.loader.exec_module(mod)
     assert not p.is_installed() and mod.NODE_CLASS_MAPPINGS == {}
     assert "WARNING" in capsys.readouterr().out
+
+
+def test_product_kernels_do_not_spill():
+    """Compiles the product kernels with -save-temps and reads the register metadata (tools/check_spills.py): no kernel may
+    touch scratch (round 1 shipped the 256x256 GEMM with a spilled VGPR).  ~30 s of hipcc."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_spills.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]

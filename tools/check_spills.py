@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Compile the PRODUCT kernels (no -DFP8MI_DIAG: co-compiled variants change each other's register allocation) with
+-save-temps and report per-kernel VGPRs, spills and scratch.  The hot loops must not touch scratch: exits 1 if a kernel
+outside ALLOW_SCRATCH has a private segment.   python tools/check_spills.py [file.hip ...]"""
+import os, re, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "fp8-mps-metal_amd", "csrc")
+files = sys.argv[1:] or ["fp8mi_gemm.hip", "fp8mi_gemv.hip", "fp8mi_skinny.hip", "fp8mi_cast.hip", "fp8mi_generic.hip"]
+# The 256x256 kernel sits AT the 256-register limit (128 accumulators + 96 fragment registers + addressing at two waves per
+# SIMD) and its allocation is fragile: unrelated edits (factoring the DMA issue into a helper, carrying two fewer lane
+# constants) moved it from 0 to 2 and to 26 spilled VGPRs.  The shipped form has none; keep it that way - check after every edit.
+TOLERATED = {}
+bad = 0
+with tempfile.TemporaryDirectory() as td:
+    for f in files:
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-gpu-rdc", "-save-temps=obj",
+                               "-c", os.path.join(SRC, f), "-o", os.path.join(td, f + ".o")], stderr=subprocess.DEVNULL)
+        asm = open(os.path.join(td, f.replace(".hip", "-hip-amdgcn-amd-amdhsa-gfx950.s"))).read()
+        for m in re.finditer(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.sgpr_spill_count:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", asm, flags=re.S):
+            name, priv, sspill, vgpr, vspill = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5))
+            short = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", name)[:90]
+            tol = max([v for k, v in TOLERATED.items() if short.startswith(k)] or [0])
+            over = vspill > tol or (priv > 0 and vspill == 0)
+            flag = "  <-- SCRATCH" if over else ("  (tolerated, outside the K loop)" if vspill else "")
+            print(f"{f:20s} vgpr {vgpr:3d}  vgpr_spill {vspill:3d}  sgpr_spill {sspill:3d}  scratch {priv:4d}  {short}{flag}")
+            bad += 1 if over else 0
+print(f"{bad} kernel(s) spill beyond what is tolerated")
+sys.exit(1 if bad else 0)
