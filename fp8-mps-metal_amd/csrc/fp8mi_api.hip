@@ -198,6 +198,14 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     switch (kernel) {
     case FP8MI_KERNEL_AUTO:
         if (fp8mi_gemv_supported(p)) return hip_result(fp8mi_launch_gemv(p, false, s), "gemv");
+        if (fp8mi_gemv_mx_supported(p)) {
+            // 2..8 rows of x on the vec-mat's weight-streaming structure (tools/check_gemv_mx.py time, MI355X): ahead of
+            // the skinny and the split-K tile kernel for M <= 4 everywhere measured (K = N = 4096: 5.6 / 6.3 vs 7.8 us;
+            // K = 14336, N = 4096: 12.2 vs 16-17 us) and for 5 <= M <= 8 once K > 4096 on matrices the tile kernel
+            // cannot fill the chip with (K = 14336, N = 4096: 14.3 vs 17.4 us; K = N = 8192: 15.1 vs 17.9 us)
+            const int64_t t64 = (p.N + 63) / 64, cus = fp8mi_cu_count();
+            if (p.M <= 4 || (p.K > 4096 && t64 < (3 * cus) / 4)) return hip_result(fp8mi_launch_gemv_mx(p, s), "gemv-mx");
+        }
         if (p.M >= 2 && p.M <= 48 && fp8mi_skinny_supported(p)) {
             // measured (tools/sweep_small_m.py): on small weight matrices the weight-streaming skinny kernel wins up
             // to M = 48 (K = N = 4096: 8.5-11.4 vs 11.4-12.6 us); on large ones (N*K >= 24 MiB) the split-K tile
@@ -217,6 +225,9 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     case FP8MI_KERNEL_GEMV:
         if (!fp8mi_gemv_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "gemv kernel needs M == 1, K %% 16 == 0, 16-byte aligned rows");
         return hip_result(fp8mi_launch_gemv(p, false, s), "gemv");
+    case FP8MI_KERNEL_GEMV_MX:
+        if (!fp8mi_gemv_mx_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "few-rows kernel needs 2 <= M <= 8, K <= 16384, K %% 16 == 0, 16-byte aligned rows");
+        return hip_result(fp8mi_launch_gemv_mx(p, s), "gemv-mx");
     case FP8MI_KERNEL_GEMV_FP32:
         if (!fp8mi_gemv_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "gemv kernel needs M == 1, K %% 16 == 0, 16-byte aligned rows");
         return hip_result(fp8mi_launch_gemv(p, true, s), "gemv-fp32");
@@ -233,6 +244,7 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
         return hip_result(fp8mi_launch_generic(p, s), "generic");
     default:
 #ifdef FP8MI_DIAG
+        if (kernel >= 70 && kernel <= 73 && fp8mi_gemv_mx_supported(p)) return hip_result(fp8mi_launch_gemv_mx_variant(p, kernel, s), "gemv-mx-variant");
         if (kernel >= 40 && kernel <= 69 && fp8mi_gemv_supported(p)) return hip_result(fp8mi_launch_gemv_variant(p, kernel, s), "gemv-variant");
 #endif
 #ifdef FP8MI_DIAG  // diagnostic library only: schedule variants of the ring kernel (7..13, 30..37), the producer / consumer kernel

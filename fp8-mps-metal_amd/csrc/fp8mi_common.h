@@ -152,6 +152,9 @@ int fp8mi_cu_count();
 int fp8mi_launch_gemv(const MMParams &p, bool fp32_only, hipStream_t s);
 int fp8mi_launch_gemv_variant(const MMParams &p, int id, hipStream_t s);  // diagnostic library only
 bool fp8mi_gemv_supported(const MMParams &p);
+int fp8mi_launch_gemv_mx(const MMParams &p, hipStream_t s);   // 2 <= M <= 8, the vec-mat's structure
+bool fp8mi_gemv_mx_supported(const MMParams &p);
+int fp8mi_launch_gemv_mx_variant(const MMParams &p, int id, hipStream_t s);  // diagnostic library only
 int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s);
 bool fp8mi_gemm_supported(const MMParams &p);
 int fp8mi_launch_generic(const MMParams &p, hipStream_t s);

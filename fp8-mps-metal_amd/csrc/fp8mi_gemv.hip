@@ -212,6 +212,179 @@ __global__ __launch_bounds__(kWaves * 64) void gemv_kernel(MMParams p_in)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 2 <= M <= 8 through the same weight-streaming structure ("few rows of x"): the reference sends these batches to its
+// one-thread-per-output kernel (fp8_mps_native.py:208; batch 4 is one of its three published shapes).  W is streamed
+// exactly as for M == 1 - 1-KiB wave-loads, x ahead of the slab, many light workgroups - and each pair of W wave-steps is
+// multiplied with the matching bytes of EVERY x row by one MFMA per row (the diagonal trick above; the matrix pipe has the
+// headroom: MX MFMAs per 2 KiB of W).  The skinny kernel (fragment-shaped loads, one workgroup per 16 rows of W) stays for
+// 9 <= M <= 64.
+template <int STEPS, int RB, int MX, int G, int kWaves = 4>
+__global__ __launch_bounds__(kWaves * 64) void gemv_mx_kernel(MMParams p_in)
+{
+    // A workgroup owns G groups of RB consecutive rows of W and keeps its K-slices of all MX rows of x in registers across
+    // them (x traffic from L2 = MX / (RB G) of the W stream; with RB G = 2 it was 4x the W bytes at M = 8 and the kernel ran
+    // 3.5x slower than at M = 2).  The W loads of group g + 1 are issued before group g is multiplied.  Each lane's diagonal
+    // elements go to LDS as they are (one masked ds_write per output cell and group instead of a 64-lane butterfly); the
+    // sums over lanes and waves are formed once, after the last group.
+    constexpr int kRows = RB * G;
+    const MMParams p = pin_params(p_in);
+    const float sr = p.scale_result ? p.scale_result[0] : 1.0f;
+    const float sa0 = p.scale_a[0];
+    const float sw0 = p.scale_b[0];
+    constexpr int kThreads = kWaves * 64;
+    __shared__ float part[kWaves][MX][kRows][16];
+    __shared__ float dump[kWaves][64];
+    __shared__ int dirty_cell[MX][kRows];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * kRows;
+    const int64_t K = p.K;
+    const uint8_t *__restrict__ X = p.A;
+    const uint8_t *__restrict__ W = p.B;
+    const int M = (int)p.M;
+    const int fr = lane & 15, fg = lane >> 4;
+    const bool on_diag = (fr >> 2) == fg;   // this lane holds element (fr, fr) of every 16x16 tile in its register fr & 3
+
+    f32x4 macc[MX][RB];
+    {   // K <= kWaves * STEPS KiB (the launcher picks the shape): one pass, x stays in registers for all groups
+        const int64_t kc = 0;
+        int64_t kb[STEPS];
+        bool kv[STEPS];
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            kb[i] = kc + (int64_t)(wave + kWaves * i) * 1024 + lane * 16;
+            kv[i] = kb[i] < K;
+        }
+        u32x4 xr[MX][STEPS];   // x first (loads return in issue order), once per workgroup and chunk
+#pragma unroll
+        for (int m = 0; m < MX; ++m)
+#pragma unroll
+            for (int i = 0; i < STEPS; ++i) {
+                xr[m][i] = u32x4{0u, 0u, 0u, 0u};
+                if (m < M && kv[i]) xr[m][i] = *(const u32x4 *)(X + (int64_t)m * p.lda + kb[i]);
+            }
+        auto load_group = [&](int g, u32x4 (&w)[RB][STEPS]) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int64_t n = row0 + g * RB + r;
+                const uint8_t *wr = W + n * p.ldb;
+#pragma unroll
+                for (int i = 0; i < STEPS; ++i) {
+                    if (n < p.N && kv[i]) w[r][i] = __builtin_nontemporal_load((const u32x4 *)(wr + kb[i]));
+                    else w[r][i] = u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+        };
+        auto mul_group = [&](int g, const u32x4 (&w)[RB][STEPS]) {
+#pragma unroll
+            for (int m = 0; m < MX; ++m)
+#pragma unroll
+                for (int r = 0; r < RB; ++r) macc[m][r] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+#pragma unroll
+                for (int i = 0; i < STEPS; i += 2) {
+                    const u32x4 w1 = i + 1 < STEPS ? w[r][i + 1] : u32x4{0u, 0u, 0u, 0u};
+                    const i32x8 a = {(int)w[r][i][0], (int)w[r][i][1], (int)w[r][i][2], (int)w[r][i][3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+#pragma unroll
+                    for (int m = 0; m < MX; ++m) {
+                        const u32x4 x0 = xr[m][i], x1 = i + 1 < STEPS ? xr[m][i + 1] : u32x4{0u, 0u, 0u, 0u};
+                        const i32x8 b = {(int)x0[0], (int)x0[1], (int)x0[2], (int)x0[3], (int)x1[0], (int)x1[1], (int)x1[2], (int)x1[3]};
+                        macc[m][r] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, macc[m][r], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MX; ++m)
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    const float d = (fr & 2) ? ((fr & 1) ? macc[m][r][3] : macc[m][r][2]) : ((fr & 1) ? macc[m][r][1] : macc[m][r][0]);
+                    // NO divergent branch here: hipcc sinks the MFMAs (and the moves that zero their unused operand halves)
+                    // into an `if (on_diag)` that holds their only use, the moves then run under a partial EXEC mask and
+                    // the matrix core - which ignores EXEC - multiplies garbage in the other lanes.  Every lane stores;
+                    // the lanes off the diagonal store to a dump slot.
+                    float *cell = on_diag ? &part[wave][m][g * RB + r][fr] : &dump[wave][lane];
+                    *cell = d;
+                }
+        };
+        u32x4 wa[RB][STEPS], wb[RB][STEPS];
+        load_group(0, wa);
+        if (p.nan_zero) {   // the reference's NaN rule for x (fp8_matmul.metal:21), under the first W loads
+#pragma unroll
+            for (int m = 0; m < MX; ++m)
+#pragma unroll
+                for (int i = 0; i < STEPS; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xr[m][i][j] = scrub_nan4(xr[m][i][j]);
+        }
+#pragma unroll
+        for (int g = 0; g < G; g += 2) {
+            if (g + 1 < G) load_group(g + 1, wb);
+            mul_group(g, wa);
+            if (g + 1 < G) {
+                if (g + 2 < G) load_group(g + 2, wa);
+                mul_group(g + 1, wb);
+            }
+        }
+    }
+    __syncthreads();
+
+    int dirty = 0;
+    const int cm = threadIdx.x / kRows, cr = threadIdx.x % kRows;  // this thread's output cell (threads 0 .. MX*kRows-1)
+    auto finish = [&](int m, int r, float sum) {
+        const int64_t n = row0 + r;
+        const float sa = p.sa_row ? p.scale_a[m] : sa0;
+        const float sw = p.sb_row ? p.scale_b[n] : sw0;
+        const float b = p.bias ? load_as_float(p.bias, p.transposed ? (int64_t)m : n, p.bias_dtype) : 0.0f;
+        store_from_float(p.C, (int64_t)m * p.ldc + n,
+                         epilogue_value(sum, sa, sw, p.bias != nullptr, b, p.scale_result != nullptr, sr, p.transposed != 0), p.out_dtype);
+    };
+    static_assert(MX * kRows <= kThreads, "one thread per output cell of the workgroup");
+    if (threadIdx.x < MX * kRows) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int wv = 0; wv < kWaves; ++wv)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sum += part[wv][cm][cr][j];
+        dirty = (p.nan_zero && sum != sum) ? 1 : 0;
+        dirty_cell[cm][cr] = dirty;
+        if (cm < M && row0 + cr < p.N && !dirty) finish(cm, cr, sum);
+    }
+    if (!__syncthreads_or(dirty)) return;
+
+    // rare path: rows of W holding NaN bytes, byte-wise reference decode
+    float *red = &part[0][0][0][0];
+    for (int m = 0; m < M; ++m)
+        for (int r = 0; r < kRows; ++r) {
+            if (!dirty_cell[m][r]) continue;  // block-uniform
+            const int64_t n = row0 + r;
+            if (n >= p.N) continue;
+            const uint8_t *wr = W + n * p.ldb;
+            const uint8_t *xm = X + (int64_t)m * p.lda;
+            float sv = 0.0f;
+            for (int64_t k = threadIdx.x; k < K; k += kThreads) sv += decode_ref(xm[k]) * decode_ref(wr[k]);
+            sv = wave_sum(sv);
+            __syncthreads();
+            if (lane == 0) red[wave] = sv;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int wv = 0; wv < kWaves; ++wv) sum += red[wv];
+                finish(m, r, sum);
+            }
+        }
+}
+
+template <int STEPS, int RB, int MX, int G, int kWaves = 4>
+int launch_mx(const MMParams &p, hipStream_t s)
+{
+    const int64_t grid = (p.N + RB * G - 1) / (RB * G);
+    return fp8mi_launch(gemv_mx_kernel<STEPS, RB, MX, G, kWaves>, dim3((unsigned)grid), dim3(kWaves * 64), s, p);
+}
+
 template <int STEPS, int RB, bool NT = true, int kWaves = 4, int ABL = 0, bool MFMA = false>
 int launch(const MMParams &p, hipStream_t s)
 {
@@ -226,6 +399,50 @@ bool fp8mi_gemv_supported(const MMParams &p)
     return p.M == 1 && p.K > 0 && (p.K % 16) == 0 && (p.ldb % 16) == 0 && (((uintptr_t)p.A) & 15u) == 0 &&
            (((uintptr_t)p.B) & 15u) == 0 && (p.N + 3) / 4 <= 0x7FFFFFFF;
 }
+
+bool fp8mi_gemv_mx_supported(const MMParams &p)
+{
+    return p.M >= 2 && p.M <= 8 && p.K > 0 && p.K <= 16384 && (p.K % 16) == 0 && (p.lda % 16) == 0 && (p.ldb % 16) == 0 && (((uintptr_t)p.A) & 15u) == 0 &&
+           (((uintptr_t)p.B) & 15u) == 0 && (p.N + 1) / 2 <= 0x7FFFFFFF;
+}
+
+int fp8mi_launch_gemv_mx_variant(const MMParams &p, int id, hipStream_t s);
+
+int fp8mi_launch_gemv_mx(const MMParams &p, hipStream_t s)
+{
+    const int64_t steps = (p.K + 4095) / 4096;   // wave-steps per wave with 4 waves; K <= 16384 (fp8mi_gemv_mx_supported)
+    if (p.M <= 2) {
+        if (steps <= 1) return launch_mx<1, 2, 2, 4>(p, s);
+        if (steps <= 2) return launch_mx<2, 2, 2, 4>(p, s);
+        return launch_mx<4, 2, 2, 4>(p, s);
+    }
+    if (p.M <= 4) {
+        if (steps <= 1) return launch_mx<1, 2, 4, 4>(p, s);
+        if (steps <= 2) return launch_mx<2, 2, 4, 4>(p, s);
+        return launch_mx<4, 2, 4, 4>(p, s);
+    }
+    if (steps <= 1) return launch_mx<1, 2, 8, 4>(p, s);
+    if (steps <= 2) return launch_mx<2, 2, 8, 8>(p, s);
+    return launch_mx<2, 2, 8, 8, 8>(p, s);   // 8 x rows, deep K: 8 waves x two wave-steps (x alone is 64 registers per lane)
+}
+
+#ifdef FP8MI_DIAG
+// few-rows kernel: <steps, rows per group, x rows, groups per workgroup>; id = 70 + variant, the x-row count follows M
+int fp8mi_launch_gemv_mx_variant(const MMParams &p, int id, hipStream_t s)
+{
+    const int64_t steps = (p.K + 4095) / 4096;
+    const int v = id - 70;
+    const int g = v == 0 ? 1 : (v == 1 ? 2 : (v == 2 ? 4 : 8));
+#define MXV(S, MXN)                                                             \
+    (g == 1 ? launch_mx<S, 2, MXN, 1>(p, s) : g == 2 ? launch_mx<S, 2, MXN, 2>(p, s) \
+     : g == 4 ? launch_mx<S, 2, MXN, 4>(p, s) : launch_mx<S, 2, MXN, 8>(p, s))
+    if (p.M <= 2) return steps <= 1 ? MXV(1, 2) : steps <= 2 ? MXV(2, 2) : MXV(4, 2);
+    if (p.M <= 4) return steps <= 1 ? MXV(1, 4) : steps <= 2 ? MXV(2, 4) : MXV(4, 4);
+    if (steps <= 2) return steps <= 1 ? MXV(1, 8) : MXV(2, 8);
+    return g == 1 ? launch_mx<2, 2, 8, 1, 8>(p, s) : g == 2 ? launch_mx<2, 2, 8, 2, 8>(p, s) : g == 4 ? launch_mx<2, 2, 8, 4, 8>(p, s) : launch_mx<2, 2, 8, 8, 8>(p, s);
+#undef MXV
+}
+#endif
 
 #ifdef FP8MI_DIAG  // launch-shape variants for A/B timing (diagnostic library only): <K-steps per wave, rows per workgroup, nt, waves>
 int fp8mi_launch_gemv_variant(const MMParams &p, int id, hipStream_t s)

@@ -38,6 +38,7 @@ ENC_REFERENCE, ENC_RNE = 0, 1
 KERNEL_AUTO, KERNEL_GEMV, KERNEL_GEMM_128, KERNEL_GENERIC, KERNEL_GEMM_256, KERNEL_GEMM_128x64, KERNEL_SKINNY = range(7)
 KERNEL_GEMM_64x128 = 14
 KERNEL_GEMV_FP32 = 18
+KERNEL_GEMV_MX = 19
 WS_COUNTER_BYTES = 4096
 EPILOGUE_TRANSPOSED = 0x100  # OR into bias_dtype (include/fp8mi.h)
 

@@ -52,7 +52,7 @@ def clean_bytes(rng, shape):
 
 
 def uses_mfma(kernel, M, K):
-    if kernel in TILE_KERNELS or kernel == L.KERNEL_SKINNY:
+    if kernel in TILE_KERNELS or kernel in (L.KERNEL_SKINNY, L.KERNEL_GEMV_MX):
         return True
     if M == 1 and kernel in (L.KERNEL_AUTO, L.KERNEL_GEMV):
         return K % 16 == 0 and K > 4096   # the vec-mat hands deep K to the matrix core; K <= 4096 (config C1) stays fp32 FMA
@@ -283,6 +283,8 @@ def _kernels_for(M, K):
             ks += [L.KERNEL_GEMV, L.KERNEL_GEMV_FP32]
         if M <= 64:
             ks.append(L.KERNEL_SKINNY)
+        if 2 <= M <= 8 and K <= 16384:
+            ks.append(L.KERNEL_GEMV_MX)
     return ks
 
 
@@ -367,6 +369,67 @@ def test_gemv_matrix_core_form_is_exact_on_narrow_range(native, cuda, oracle):
     got = native.fp8_scaled_mm(dev(x, cuda), dev(W, cuda), torch.ones(1), torch.ones(1), kernel=L.KERNEL_GEMV,
                                nan_mode=L.NAN_PROPAGATE).cpu().numpy()
     assert np.isnan(got).all()  # a NaN in x poisons every output
+
+
+@pytest.mark.parametrize("M", [2, 3, 4, 5, 7, 8])
+def test_few_rows_kernel(native, cuda, oracle, M):
+    """2..8 activation rows on the vec-mat's weight-streaming structure (FP8MI_KERNEL_GEMV_MX; the reference runs these
+    through fp8_scaled_matmul_kernel, fp8_matmul.metal:99-147): every launch shape (K <= 4096 / 8192 / 16384 per row
+    count), ragged N, NaN bytes in both operands under both NaN modes, per-row scales, bias, scale_result, bf16."""
+    for (K, N) in ((16, 1), (272, 70), (1040, 33), (4096, 513), (8192, 64), (14336, 257), (16384, 40)):
+        rng = np.random.default_rng(M * 1000 + K + N)
+        X = clean_bytes(rng, (M, K))
+        W = clean_bytes(rng, (N, K))
+        sa = rng.uniform(0.005, 0.02, size=M).astype(np.float32)
+        sb = rng.uniform(0.005, 0.02, size=N).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        a = check_mm(oracle, native, cuda, X, W, [0.01], [0.02], kernel=L.KERNEL_GEMV_MX)
+        if K > 16:
+            b = check_mm(oracle, native, cuda, X, W, [0.01], [0.02])   # what AUTO picks agrees (the same kernel for M <= 4)
+            if M <= 4:
+                assert torch.equal(a, b)
+        check_mm(oracle, native, cuda, X, W, sa, sb, kernel=L.KERNEL_GEMV_MX, bias=bias, scale_result=0.25)
+        check_mm(oracle, native, cuda, X, W, sa, sb, kernel=L.KERNEL_GEMV_MX, bias=bias, out_dtype=torch.bfloat16)
+        X[M - 1, K // 2] = 0x7F
+        W[N - 1, K - 1] = 0xFF
+        W[0, 0] = 0x7F
+        check_mm(oracle, native, cuda, X, W, sa, sb, kernel=L.KERNEL_GEMV_MX, bias=bias)     # reference: NaN byte = 0.0
+        got = native.fp8_scaled_mm(dev(X, cuda), dev(W, cuda), torch.ones(1), torch.ones(1), kernel=L.KERNEL_GEMV_MX,
+                                   nan_mode=L.NAN_PROPAGATE).cpu().numpy()
+        nan = np.isnan(got)
+        expect = np.zeros((M, N), bool)
+        expect[M - 1, :] = True
+        expect[:, N - 1] = True
+        expect[:, 0] = True
+        assert np.array_equal(nan, expect)                                                    # OCP: exactly the poisoned row / columns
+    with pytest.raises(RuntimeError):   # outside its envelope the explicit id refuses (AUTO falls through to the other kernels)
+        native.fp8_scaled_mm(torch.zeros(9, 64, dtype=torch.uint8, device=cuda), torch.zeros(8, 64, dtype=torch.uint8, device=cuda),
+                             torch.ones(1), torch.ones(1), kernel=L.KERNEL_GEMV_MX)
+    with pytest.raises(RuntimeError):
+        native.fp8_scaled_mm(torch.zeros(4, 16400, dtype=torch.uint8, device=cuda), torch.zeros(8, 16400, dtype=torch.uint8, device=cuda),
+                             torch.ones(1), torch.ones(1), kernel=L.KERNEL_GEMV_MX)
+
+
+def test_few_rows_kernel_is_exact_on_narrow_range_and_matches_rows(native, cuda, oracle):
+    """As for the vec-mat: operands within a 2^12 product range are summed exactly by the matrix core, so the few-rows
+    kernel must meet the fp32 bound there (a wrong lane / register in the diagonal extraction cannot hide behind the
+    hardware tolerance), and row m of its result equals the M = 1 kernel's result for x[m] bit for bit at deep K."""
+    rng = np.random.default_rng(78)
+    for (M, K, N) in ((2, 6144, 300), (5, 6144, 300), (4, 14336, 129), (8, 16384, 33), (8, 4096, 77), (3, 2048, 130)):
+        X = (0x28 + rng.integers(0, 0x20, size=(M, K))).astype(np.uint8)
+        W = (0x28 + rng.integers(0, 0x20, size=(N, K))).astype(np.uint8)
+        check_mm(oracle, native, cuda, X, W, [0.5], [2.0], kernel=L.KERNEL_GEMV_MX, tol=MM_TOL)
+    # transposed epilogue (the sharded linear's form): bias per output ROW of this call, scales in the swapped order
+    M, K, N = 6, 8192, 48
+    X = clean_bytes(rng, (M, K))
+    W = clean_bytes(rng, (N, K))
+    sx = rng.uniform(0.005, 0.02, size=M).astype(np.float32)
+    bias_m = rng.standard_normal(M).astype(np.float32)
+    t = native.fp8_scaled_mm(dev(X, cuda), dev(W, cuda), dev(sx, cuda), torch.full((1,), 0.03), bias=dev(bias_m, cuda),
+                             kernel=L.KERNEL_GEMV_MX, transposed_epilogue=True).cpu().numpy()
+    exact = oracle.scaled_mm(X, W, sx, [0.03], accumulate="f64") + bias_m[:, None]
+    bound = oracle.abs_dot_bound(X, W, sx, [0.03]) + np.abs(bias_m)[:, None]
+    assert np.all(np.abs(t - exact) <= MFMA_TOL * bound + 1e-30)
 
 
 @pytest.mark.parametrize("kernel", TILE_KERNELS)
