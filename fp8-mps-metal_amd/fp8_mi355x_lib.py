@@ -39,6 +39,7 @@ KERNEL_AUTO, KERNEL_GEMV, KERNEL_GEMM_128, KERNEL_GENERIC, KERNEL_GEMM_256, KERN
 KERNEL_GEMM_64x128 = 14
 KERNEL_GEMV_FP32 = 18
 KERNEL_GEMV_MX = 19
+KERNEL_GEMM_256W = 20
 WS_COUNTER_BYTES = 4096
 EPILOGUE_TRANSPOSED = 0x100  # OR into bias_dtype (include/fp8mi.h)
 
