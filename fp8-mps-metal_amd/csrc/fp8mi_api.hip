@@ -242,11 +242,12 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
         return hip_result(fp8mi_launch_gemm(p, kernel, s), "gemm");
     case FP8MI_KERNEL_GEMM_256W:
         if (!fp8mi_gemm256_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "256x256 one-wave-per-SIMD kernel needs M %% 256 == 0, N %% 256 == 0, K %% 128 == 0, K >= 256, 16-byte aligned rows, no split-K");
-        return hip_result(fp8mi_launch_gemm256(p, s), "gemm256");
+        return hip_result(fp8mi_launch_gemm256(p, 0, s), "gemm256");
     case FP8MI_KERNEL_GENERIC:
         return hip_result(fp8mi_launch_generic(p, s), "generic");
     default:
 #ifdef FP8MI_DIAG
+        if (kernel >= 80 && kernel <= 119 && fp8mi_gemm256_supported(p)) return hip_result(fp8mi_launch_gemm256(p, kernel - 80, s), "gemm256-variant");
         if (kernel >= 70 && kernel <= 73 && fp8mi_gemv_mx_supported(p)) return hip_result(fp8mi_launch_gemv_mx_variant(p, kernel, s), "gemv-mx-variant");
         if (kernel >= 40 && kernel <= 69 && fp8mi_gemv_supported(p)) return hip_result(fp8mi_launch_gemv_variant(p, kernel, s), "gemv-variant");
 #endif

@@ -24,105 +24,157 @@ namespace {
 constexpr int kBM = 256, kBN = 256, kThreads256 = 256;   // 4 waves, one per SIMD
 constexpr int kSlotBytes = (kBM + kBN) * BK;   // 64 KiB: A's 256 rows, then B's
 constexpr int kRing256 = 2 * kSlotBytes;
+typedef float f32x32 __attribute__((ext_vector_type(32)));   // one fragment row of accumulators (asm operand type)
+constexpr int kDumpWave = 32 * 1024;   // a wave's quarter of the ring: 4 fragment rows x (16 rows x 512 B) of fp32 accumulators
+constexpr int kDumpRow = 8 * 1024;     // one fragment row
 
-// one fragment row (16 rows x 128 columns of the wave tile) through the fused epilogue, staged through the wave's corner
-// of the idle ring so that every global store writes whole lines (cf. epilogue_staged, fp8mi_gemm_epi.h)
-template <int OUT>
-FP8MI_DEVICE void epilogue_row(const MMParams &p, const EpiScalars &es, const f32x4 (&acc)[8], const float (&sbv)[8][4],
-                               const float (&bv)[8][4], uint8_t *buf, int64_t row0 /* global m of the fragment row */,
-                               int64_t col0 /* global n of the wave tile */, int lane)
+// The epilogue's rounding sequence is the ring kernels': (acc * sa) * sb, + bias, * sr - four roundings.  With the
+// switches as template parameters hipcc would contract the multiply-add into an fma (one rounding less, different bits).
+#pragma clang fp contract(off)
+
+// Per-wave epilogue tables in the LDS behind the ring, fp32, one entry per row / column of the wave tile: scale_a (or the
+// per-tensor value), scale_b, bias along n, bias along m (transposed).  Each lane fetches its two entries of every table
+// at kernel entry (loads in flight under the K loop, uniform type switches out of the epilogue's inner loop) and writes
+// them to the LDS after the loop.
+constexpr int kTabBytes = 4 * 512;                       // per wave
+constexpr int kTabBase = kRing256 + kFlagBytes;
+struct TabRegs {
+    float sa[2], sb[2], bn[2], bm[2];
+};
+
+FP8MI_DEVICE TabRegs load_tables(const MMParams &p, int64_t m_wave, int64_t n_wave, int lane)
+{
+    TabRegs t;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = lane + 64 * h;
+        t.sa[h] = p.scale_a[p.sa_row ? m_wave + i : 0];
+        t.sb[h] = p.scale_b[p.sb_row ? n_wave + i : 0];
+        t.bn[h] = 0.0f;
+        t.bm[h] = 0.0f;
+    }
+    if (p.bias != nullptr) {
+        const int64_t base = p.transposed ? m_wave : n_wave;
+        float b[2];
+        if (p.bias_dtype == FP8MI_F32) {
+            b[0] = ((const float *)p.bias)[base + lane];
+            b[1] = ((const float *)p.bias)[base + lane + 64];
+        } else if (p.bias_dtype == FP8MI_BF16) {
+            b[0] = (float)((const __bf16 *)p.bias)[base + lane];
+            b[1] = (float)((const __bf16 *)p.bias)[base + lane + 64];
+        } else {
+            b[0] = (float)((const _Float16 *)p.bias)[base + lane];
+            b[1] = (float)((const _Float16 *)p.bias)[base + lane + 64];
+        }
+        if (p.transposed) { t.bm[0] = b[0]; t.bm[1] = b[1]; }
+        else { t.bn[0] = b[0]; t.bn[1] = b[1]; }
+    }
+    return t;
+}
+
+FP8MI_DEVICE void store_tables(const TabRegs &t, float *tab, int lane)
+{
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        tab[lane + 64 * h] = t.sa[h];
+        tab[128 + lane + 64 * h] = t.sb[h];
+        tab[256 + lane + 64 * h] = t.bn[h];
+        tab[384 + lane + 64 * h] = t.bm[h];
+    }
+}
+
+// Fused epilogue of one HALF of the wave tile (fragment rows 4 half .. 4 half + 3, i.e. 64 rows x 128 columns), read back
+// ROW-WISE from the accumulator dump (gen_gemm256_loop.py): a lane takes the 16-byte chunk at position `pos` of row r,
+// which holds the columns 4 (pos ^ (r & 15)) .. + 3, so every global store instruction writes whole rows (512 B of fp32
+// per 32 lanes, 256 B of 16-bit) without a second trip through the LDS.  Returns the sum of everything read (NaN vote).
+template <int OUT, bool BIAS, bool TRANSPOSED>
+FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, float sr, const uint8_t *dump, const float *tab, int half, int64_t m_wave, int64_t n_wave,
+                                 int lane)
 {
     constexpr int kEsz = OUT == FP8MI_F32 ? 4 : 2;
-    constexpr int kRowBytes = 128 * kEsz, kStride = kRowBytes + 16, kCPR = kRowBytes / 16, kRPI = 64 / kCPR, kNI = 16 / kRPI;
-    const int fr = lane & 15, fg = lane >> 4;
-    const bool has_bias = p.bias != nullptr, has_sr = p.scale_result != nullptr;
-    const float sa = p.sa_row ? p.scale_a[row0 + fr] : es.sa0;
-    const float brow = (has_bias && p.transposed) ? load_as_float(p.bias, row0 + fr, p.bias_dtype) : 0.0f;
-#pragma unroll
-    for (int tn = 0; tn < 8; ++tn) {
+    const int pos = lane & 31, rsub = lane >> 5;   // two rows per instruction
+    f32x4 nan_sum = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+    for (int it = 0; it < 32; ++it) {              // 64 rows, two at a time
+        const int rr = it * 2 + rsub;              // row inside the half: fragment row rr >> 4, row rr & 15
+        const int r = rr & 15;
+        const f32x4 q = *(const f32x4 *)(dump + (rr >> 4) * kDumpRow + r * 512 + pos * 16);
+        nan_sum += q;
+        const int col = (pos ^ r) * 4;             // this chunk's first column inside the wave tile
+        const int row = half * 64 + rr;
+        const float sa = tab[row];
+        const f32x4 sb4 = *(const f32x4 *)(tab + 128 + col);
+        const f32x4 bn4 = *(const f32x4 *)(tab + 256 + col);
+        const float bm = tab[384 + row];
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float r = p.transposed ? (acc[tn][j] * sbv[tn][j]) * sa : (acc[tn][j] * sa) * sbv[tn][j];
-            if (has_bias) r = r + (p.transposed ? brow : bv[tn][j]);
-            if (has_sr) r = r * es.sr;
-            v[j] = r;
+            float x = TRANSPOSED ? (q[j] * sb4[j]) * sa : (q[j] * sa) * sb4[j];
+            if (BIAS) x = x + (TRANSPOSED ? bm : bn4[j]);
+            v[j] = x * sr;                          // (sr = 1.0f when there is no scale_result: exact)
         }
-        uint8_t *d = buf + fr * kStride + (tn * 16 + fg * 4) * kEsz;
+        uint8_t *dst = (uint8_t *)p.C + ((m_wave + row) * p.ldc + n_wave + col) * kEsz;
         if (OUT == FP8MI_F32) {
-            *(f32x4 *)d = f32x4{v[0], v[1], v[2], v[3]};
+            __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, (f32x4 *)dst);
         } else if (OUT == FP8MI_BF16) {
             __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1], h2 = (__bf16)v[2], h3 = (__bf16)v[3];
-            *(u32x2 *)d = u32x2{(uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16),
-                                (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16)};
+            __builtin_nontemporal_store(u32x2{(uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16),
+                                              (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16)},
+                                        (u32x2 *)dst);
         } else {
             _Float16 h0 = (_Float16)v[0], h1 = (_Float16)v[1], h2 = (_Float16)v[2], h3 = (_Float16)v[3];
-            *(u32x2 *)d = u32x2{(uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16),
-                                (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16)};
+            __builtin_nontemporal_store(u32x2{(uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16),
+                                              (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16)},
+                                        (u32x2 *)dst);
         }
     }
-    const int rrow = lane / kCPR, rchunk = lane % kCPR;
-    uint8_t *grow = (uint8_t *)p.C + (row0 * p.ldc + col0) * kEsz;
-#pragma unroll
-    for (int i = 0; i < kNI; ++i) {
-        const int r = i * kRPI + rrow;
-        u32x4 q = *(const u32x4 *)(buf + r * kStride + rchunk * 16);  // same wave wrote and reads: DS operations of one wave execute in order
-        __builtin_nontemporal_store(q, (u32x4 *)(grow + (int64_t)r * p.ldc * kEsz + rchunk * 16));
-    }
-}
-
-template <int OUT, int TM>
-FP8MI_DEVICE void epilogue_rows(const MMParams &p, const EpiScalars &es, const float (&sbv)[8][4], const float (&bv)[8][4],
-                                uint8_t *buf, int64_t m_wave, int64_t n_wave, int lane)
-{
-    if constexpr (TM < 8) {
-        f32x4 r[8];
-        read_acc_row<TM>(r);
-        epilogue_row<OUT>(p, es, r, sbv, bv, buf, m_wave + TM * 16, n_wave, lane);
-        epilogue_rows<OUT, TM + 1>(p, es, sbv, bv, buf, m_wave, n_wave, lane);
-    }
-}
-
-template <int TM>
-FP8MI_DEVICE void sum_acc_rows(f32x4 &t)
-{
-    if constexpr (TM < 8) {
-        f32x4 r[8];
-        read_acc_row<TM>(r);
-#pragma unroll
-        for (int tn = 0; tn < 8; ++tn) t += r[tn];
-        sum_acc_rows<TM + 1>(t);
-    }
+    return nan_sum;
 }
 
 template <int OUT>
-FP8MI_DEVICE void epilogue256(const MMParams &p, const EpiScalars &es, uint8_t *smem, int64_t m0, int64_t n0, int wave, int wm0,
-                              int wn0, int lane)
+FP8MI_DEVICE f32x4 epilogue_half_flags(const MMParams &p, float sr, const uint8_t *dump, const float *tab, int half, int64_t m_wave,
+                                       int64_t n_wave, int lane)
 {
-    constexpr int kEsz = OUT == FP8MI_F32 ? 4 : 2;
-    constexpr int kStride = 128 * kEsz + 16;
-    uint8_t *buf = smem + wave * (16 * kStride);
-    const int fg = lane >> 4;
-    const bool has_bias = p.bias != nullptr;
-    float sbv[8][4], bv[8][4];
-#pragma unroll
-    for (int tn = 0; tn < 8; ++tn)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t n = n0 + wn0 + tn * 16 + fg * 4 + j;
-            sbv[tn][j] = p.sb_row ? p.scale_b[n] : es.sb0;
-            bv[tn][j] = (has_bias && !p.transposed) ? load_as_float(p.bias, n, p.bias_dtype) : 0.0f;
-        }
-    epilogue_rows<OUT, 0>(p, es, sbv, bv, buf, m0 + wm0, n0 + wn0, lane);
+    if (p.bias == nullptr) {
+        if (p.transposed) return epilogue_half<OUT, false, true>(p, sr, dump, tab, half, m_wave, n_wave, lane);
+        return epilogue_half<OUT, false, false>(p, sr, dump, tab, half, m_wave, n_wave, lane);
+    }
+    if (p.transposed) return epilogue_half<OUT, true, true>(p, sr, dump, tab, half, m_wave, n_wave, lane);
+    return epilogue_half<OUT, true, false>(p, sr, dump, tab, half, m_wave, n_wave, lane);
 }
 
+FP8MI_DEVICE f32x4 epilogue_half_any(const MMParams &p, float sr, const uint8_t *dump, const float *tab, int half, int64_t m_wave,
+                                     int64_t n_wave, int lane)
+{
+    if (p.out_dtype == FP8MI_F32) return epilogue_half_flags<FP8MI_F32>(p, sr, dump, tab, half, m_wave, n_wave, lane);
+    if (p.out_dtype == FP8MI_BF16) return epilogue_half_flags<FP8MI_BF16>(p, sr, dump, tab, half, m_wave, n_wave, lane);
+    return epilogue_half_flags<FP8MI_F16>(p, sr, dump, tab, half, m_wave, n_wave, lane);
+}
+
+#ifdef FP8MI_STAMP  // diagnostic build only: phase stamps of wave 0 of every workgroup (tools/stamp_gemm256.py)
+__device__ unsigned long long g_stamp256[1024 * 8];
+#define STAMP256(i)                                                                 \
+    do {                                                                            \
+        unsigned long long t_;                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");  \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) g_stamp256[blockIdx.x * 8 + (i)] = t_; \
+    } while (0)
+#else
+#define STAMP256(i) do { } while (0)
+#endif
+
+template <int V>   // V = 0: the product schedule; others only in the diagnostic build (gen_gemm256_loop.py VARIANTS)
 __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int tiles_m, int tiles_n, int nwg)
 {
+#ifdef FP8MI_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_stamp256[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+#endif
+    STAMP256(0);
     const MMParams p = pin_params(p_in);
     FP8MI_PIN_S(tiles_m); FP8MI_PIN_S(tiles_n); FP8MI_PIN_S(nwg);
-    const EpiScalars es = load_epi_scalars(p);
-    __shared__ __attribute__((aligned(16))) uint8_t smem[kRing256 + kFlagBytes];
-    if (threadIdx.x == 0) *(volatile int *)(smem + kRing256) = 0;  // NaN verdict word (ordered by the K loop's barriers)
+    const float sr_v = p.scale_result ? p.scale_result[0] : 1.0f;   // in flight under the K loop
+    __shared__ __attribute__((aligned(16))) uint8_t smem[kRing256 + kFlagBytes + 4 * kTabBytes];
+    if (threadIdx.x == 0) *(__attribute__((address_space(3))) volatile int *)(lds_void *)(smem + kRing256) = 0;  // NaN verdict word (ordered by the K loop's barriers)
 
     int tile_m, tile_n, kslice, wg;
     tile_of_block(blockIdx.x, nwg, tiles_m, tiles_n, tile_m, tile_n, kslice, wg);
@@ -130,6 +182,7 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm0 = (wave & 1) * 128, wn0 = (wave >> 1) * 128;
+    const TabRegs tabs = load_tables(p, m0 + wm0, n0 + wn0, lane);   // in flight under the K loop
 
     // raw buffer descriptors (stride 0, range-checked) rebased to this tile's first row; whole tiles only
     const uint64_t pa = (uint64_t)(p.A + m0 * p.lda), pb = (uint64_t)(p.B + n0 * p.ldb);
@@ -141,54 +194,87 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
     rb[0] = __builtin_amdgcn_readfirstlane(rb[0]); rb[1] = __builtin_amdgcn_readfirstlane(rb[1]);
     rb[2] = __builtin_amdgcn_readfirstlane(rb[2]);
 
-    // staging plan (fp8mi_gemm.hip): wave w stages the 1-KiB groups w, w + 4, ... of both operands; lane -> (row, swizzled chunk)
-    const int row0 = wave * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ (((wave & 1) * 4 + (lane >> 4)) & 7);
-    const uint32_t va0 = (uint32_t)(row0 * p.lda + chunk * 16), vb0 = (uint32_t)(row0 * p.ldb + chunk * 16);
     const uint32_t sa = (uint32_t)__builtin_amdgcn_readfirstlane((int)(32 * p.lda)), sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(32 * p.ldb));
-    // fragment read addresses: row r = lane & 15, lane group g reads chunks g and 4 + g of its row, swizzled by (r >> 1)
-    const int fr = lane & 15, fg = lane >> 4;
-    const uint32_t off1 = (uint32_t)(fr * BK + ((fg ^ (fr >> 1)) << 4)), off2 = (uint32_t)(fr * BK + (((4 + fg) ^ (fr >> 1)) << 4));
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void *)smem;
     const uint32_t vscale = (uint32_t)kScaleOne;
     const int nk = (int)(p.K / BK);  // >= 2 (host)
 
-    auto run = [&](bool scrub) {
+    STAMP256(1);
+    // NaN bytes: the epilogue sums the accumulators it reads anyway; a NaN proves a NaN byte took part in this tile (finite
+    // e4m3 products cannot overflow fp32).  Only then - reference semantics, fp8_matmul.metal:21 - the workgroup redoes
+    // the tile with every fragment scrubbed and stores it again; clean inputs pay one barrier.
+    typedef __attribute__((address_space(3))) volatile int lds_vint;
+    lds_vint *flag = (lds_vint *)(lds_void *)(smem + kRing256);
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        // (everything below derives from a lane id produced INSIDE the loop by an opaque statement: visible as loop
+        //  invariants, hipcc hoists the ~20 registers of asm operands and epilogue addresses out of the loop and keeps
+        //  them in scratch across the epilogue)
+        int lane_l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_l));
+        // staging plan (fp8mi_gemm.hip): wave w stages the 1-KiB groups w, w + 4, ... of both operands; lane -> (row, swizzled chunk)
+        const int row0 = wave * 8 + (lane_l >> 3);
+        const int chunk = (lane_l & 7) ^ (((wave & 1) * 4 + (lane_l >> 4)) & 7);
+        const uint32_t va0 = (uint32_t)(row0 * p.lda + chunk * 16), vb0 = (uint32_t)(row0 * p.ldb + chunk * 16);
+        // fragment read addresses: row r = lane & 15, lane group g reads chunks g and 4 + g of its row, swizzled by (r >> 1)
+        const int fr = lane_l & 15, fg = lane_l >> 4;
+        const uint32_t off1 = (uint32_t)(fr * BK + ((fg ^ (fr >> 1)) << 4)), off2 = (uint32_t)(fr * BK + (((4 + fg) ^ (fr >> 1)) << 4));
         uint32_t alo_c = lds0 + wm0 * BK + off1, ahi_c = lds0 + wm0 * BK + off2;
         uint32_t blo_c = lds0 + kBM * BK + wn0 * BK + off1, bhi_c = lds0 + kBM * BK + wn0 * BK + off2;
         uint32_t alo_n = alo_c + kSlotBytes, ahi_n = ahi_c + kSlotBytes, blo_n = blo_c + kSlotBytes, bhi_n = bhi_c + kSlotBytes;
         uint32_t m0_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + wave * 1024)), m0_n = m0_c + kSlotBytes;
         uint32_t k2 = 0, nloop = (uint32_t)(nk - 2), t0;
-        if (!scrub) {
-            FP8MI_GEMM256_LOOP();
+        // L2 prefetch (gen_gemm256_loop.py pf_group): the 32 tiles an XCD runs at one time are 4 m-tiles x 8 n-tiles of one group
+        // (tile_of_block), so an A panel has 8 readers and a B panel 4; each warms its share of the lines of a later stage:
+        // wave 0 rows 64 (tile_m & 3) .. + 63 of its B panel, wave 1 rows 32 (tile_n & 7) .. + 31 of its A panel (other lanes
+        // point outside the buffer: no access).  Speed only: whoever else reads the panel finds the lines in the L2.
+        const uint32_t pfoff = wave == 0 ? (uint32_t)((64 * (tile_m & 3) + lane_l) * p.ldb)
+                               : (wave == 1 && lane_l < 32) ? (uint32_t)((32 * (tile_n & 7) + lane_l) * p.lda) : kOOB;
+        const u32x4 rpf = wave == 0 ? rb : ra;
+        const uint32_t klast = (uint32_t)((nk - 1) * BK);
+        // accumulator dump (gen_gemm256_loop.py): row fr of each fragment row, 16-byte chunk (4 tn + fg) ^ fr
+        const uint32_t drow = lds0 + wave * kDumpWave + fr * 512, dkey = (uint32_t)((fg ^ fr) << 4);
+        f32x32 acc4, acc5, acc6, acc7;   // fragment rows 4..7, pinned to a[128:255] by the asm
+        if (pass == 0) {
+            if constexpr (V == 0) {
+                FP8MI_GEMM256_LOOP();
+            }
+#ifdef FP8MI_DIAG
+#define X(v) else if constexpr (V == v) { FP8MI_GEMM256_LOOP_V##v(); }
+            FP8MI_GEMM256_VARIANTS
+#undef X
+#endif
         } else {
             uint32_t vt0, vt1;
             FP8MI_GEMM256_LOOP_SCRUB();
             (void)vt0; (void)vt1;
         }
         (void)t0;
-    };
-    run(false);
-
-    // ---- end of the K loop: one barrier frees the ring and carries the NaN verdict ----
-    volatile int *flag = (volatile int *)(smem + kRing256);
-    if (p.nan_zero) {
-        f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
-        sum_acc_rows<0>(t);
-        const float s = (t[0] + t[1]) + (t[2] + t[3]);
-        if (s != s) *flag = 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (p.nan_zero && *flag) {  // workgroup-uniform
-        run(true);
+        if (pass == 0) STAMP256(2);
+        int lane_e;
+        int64_t m_wave = m0 + wm0, n_wave = n0 + wn0;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e), "+s"(m_wave), "+s"(n_wave));
+        const uint8_t *dump = smem + wave * kDumpWave;
+        float *tab = (float *)(smem + kTabBase + wave * kTabBytes);
+        if (pass == 0) store_tables(tabs, tab, lane_e);
+        const float sr = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sr_v)));
+        f32x4 t = epilogue_half_any(p, sr, dump, tab, 0, m_wave, n_wave, lane_e);
+        if (pass == 0) STAMP256(3);
+        FP8MI_GEMM256_DUMP_HI();
+        t += epilogue_half_any(p, sr, dump, tab, 1, m_wave, n_wave, lane_e);
+        if (!p.nan_zero || pass == 1) break;
+        const float sum = (t[0] + t[1]) + (t[2] + t[3]);
+        if (sum != sum) *flag = 1;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();   // every wave has voted (and is done with its dump)
+        if (!__builtin_amdgcn_readfirstlane(*flag)) break;  // workgroup-uniform
     }
-
-    if (p.out_dtype == FP8MI_F32) epilogue256<FP8MI_F32>(p, es, smem, m0, n0, wave, wm0, wn0, lane);
-    else if (p.out_dtype == FP8MI_BF16) epilogue256<FP8MI_BF16>(p, es, smem, m0, n0, wave, wm0, wn0, lane);
-    else epilogue256<FP8MI_F16>(p, es, smem, m0, n0, wave, wm0, wn0, lane);
+#ifdef FP8MI_STAMP
+    STAMP256(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP256(5);
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_stamp256[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 }  // namespace
@@ -201,9 +287,24 @@ bool fp8mi_gemm256_supported(const MMParams &p)
            ((p.ldc * esz) % 16) == 0 && (((uintptr_t)p.C) % 16) == 0 && (p.M / kBM) * (p.N / kBN) <= 0x7FFFFFFF;
 }
 
-int fp8mi_launch_gemm256(const MMParams &p, hipStream_t s)
+#ifdef FP8MI_STAMP
+extern "C" int fp8mi_debug_read_stamps256(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp256), sizeof(unsigned long long) * n);
+}
+#endif
+
+int fp8mi_launch_gemm256(const MMParams &p, int variant, hipStream_t s)
 {
     const int64_t tm = p.M / kBM, tn = p.N / kBN;
     const unsigned grid = (unsigned)(tm * tn);
-    return fp8mi_launch(gemm256_kernel, dim3(grid), dim3(kThreads256), s, p, (int)tm, (int)tn, (int)grid);
+    switch (variant) {
+    case 0: return fp8mi_launch(gemm256_kernel<0>, dim3(grid), dim3(kThreads256), s, p, (int)tm, (int)tn, (int)grid);
+#ifdef FP8MI_DIAG
+#define X(v) case v: return fp8mi_launch(gemm256_kernel<v>, dim3(grid), dim3(kThreads256), s, p, (int)tm, (int)tn, (int)grid);
+    FP8MI_GEMM256_VARIANTS
+#undef X
+#endif
+    default: return FP8MI_E_ENUM;
+    }
 }

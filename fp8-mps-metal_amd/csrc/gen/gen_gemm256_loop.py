@@ -7,7 +7,16 @@ re-clusters all 64 MFMAs of a K-step regardless of scheduling fences, and it can
 next to 128 fragment VGPRs without shuffling them.  The loop is therefore written with fixed
 physical registers:
 
-    a[0:255]     accumulators, a[(tn * 8 + tm) * 4 + j]   (W fragment tn = MFMA operand A, X fragment tm = operand B)
+    a[0:255]     accumulators, a[(tm * 8 + tn) * 4 + j]   (W fragment tn = MFMA operand A, X fragment tm = operand B)
+    v[120:127]   LDS addresses of the accumulator dump
+
+The accumulators leave through the LDS: behind the last MFMA and a barrier (the ring is idle then) the loop writes fragment
+rows tm = 0..3 of every wave into the wave's 32-KiB quarter of the ring as plain fp32 rows (16 rows x 512 B per fragment
+row, 16-byte chunks XOR-swizzled by the row so that the writes and the row-wise read-back are bank-conflict free); rows
+4..7 stay in a[128:255] and are declared to the compiler as four 32-float OUTPUT operands pinned there, which a second
+small asm statement (FP8MI_GEMM256_DUMP_HI) takes as inputs once the HIP epilogue has consumed the first half.  The HIP
+side never touches an AGPR itself: hidden liveness in AGPRs does not survive hipcc (it parks its own values there), and
+reading 1024-bit AGPR operands element-wise made it spill.
     v[128:191]   W fragments (rows of B, n), 8 registers per fragment tn
     v[192:255]   X fragments (rows of A, m), 8 registers per fragment tm
 
@@ -24,14 +33,40 @@ one barrier per K-step.  Usage: python gen_gemm256_loop.py > ../fp8mi_gemm256_lo
 """
 import sys
 
-DMA_FIRST = 8      # index of the MFMA after which the first DMA of a step is issued (>= 8: behind the barrier)
-DMA_EVERY = 3      # MFMAs between DMA instructions
-XDELAY = 1         # X fragment tm is re-read this many MFMAs after MFMA(7, tm)
-BARRIER_AFTER = 7  # the step's barrier sits behind this MFMA index
+# the product schedule; VARIANTS (diagnostic build only) override single entries for A/B timing
+PRODUCT = dict(
+    dma_first=8,      # index of the MFMA after which the first DMA of a step is issued (>= barrier_after + 1)
+    dma_every=3,      # MFMAs between DMA instructions
+    xdelay=1,         # X fragment tm is re-read this many MFMAs after MFMA(7, tm)
+    barrier_after=7,  # the step's barrier sits behind this MFMA index
+    pf=2,             # > 0: each step one L2 prefetch instruction per wave for the stage `pf` steps ahead of the DMA's (see pf_group)
+    pf_at=56,         # index of the MFMA after which it is issued (behind the step's last DMA)
+    # timing-only ablations (wrong results): which parts of the steady-state step are left out
+    no_vmwait=False, no_dma=False, no_barrier=False, no_reads=False, no_mfma=False,
+)
+VARIANTS = {
+    1: dict(no_vmwait=True),
+    2: dict(no_dma=True),
+    3: dict(no_barrier=True),
+    4: dict(no_reads=True),
+    5: dict(no_mfma=True),
+    6: dict(dma_every=2),
+    7: dict(dma_every=1),
+    8: dict(dma_every=4),
+    9: dict(xdelay=0),
+    10: dict(no_dma=True, no_reads=True, no_barrier=True),
+    11: dict(pf=0),
+    12: dict(pf=3),
+    13: dict(pf=1),
+    14: dict(barrier_after=3, dma_first=4),
+    15: dict(pf=4),
+    16: dict(pf_at=20),
+}
+P = dict(PRODUCT)
 
 WF = lambda tn: 128 + 8 * tn
 XF = lambda tm: 192 + 8 * tm
-ACC = lambda tn, tm: (tn * 8 + tm) * 4
+ACC = lambda tn, tm: (tm * 8 + tn) * 4   # fragment row tm = one block of 32 AGPRs = one asm output operand
 
 
 def mfma(tn, tm):
@@ -74,6 +109,14 @@ def dma_block(slot_m0, kreg, first=True):
     return groups
 
 
+def pf_group():
+    """L2 prefetch: one dword per 128-byte line of this wave's share of a later stage (the tiles that run on one XCD at one
+    time share A and B panels; each warms 1/8 of its A and 1/4 of its B panel - fp8mi_gemm256.hip sets up the offsets).
+    The data is discarded; the load is younger than the step's DMAs, so the counted vmcnt wait lets it stay in flight."""
+    return [f"s_add_u32 %[t0], %[k2], {hex(128 * P['pf'])}", "s_min_u32 %[t0], %[t0], %[klast]",
+            "buffer_load_dword v119, %[pfoff], %[rpf], %[t0] offen"]
+
+
 def swap_slots():
     out = []
     for r in ("alo", "ahi", "blo", "bhi"):
@@ -98,31 +141,48 @@ def step(dma, reads):
     for tm in range(8):
         pre[tm].append(f"s_waitcnt lgkmcnt({min(15, 2 * (7 - tm) + 2)})")
     if reads:
-        post[BARRIER_AFTER] += ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]
-        first_row_after_barrier = BARRIER_AFTER // 8
-        for tn in range(first_row_after_barrier + 1):  # W fragments of the rows already done
-            post[BARRIER_AFTER] += rdW(tn, "n")
-        for tn in range(first_row_after_barrier + 1, 7):
-            post[8 * tn + 7] += rdW(tn, "n")
+        BARRIER_AFTER = P["barrier_after"]
+        vm = 1 if (P["pf"] and dma) else 0   # the previous step's prefetch may stay in flight (tail steps: drain everything)
+        post[BARRIER_AFTER] += ["s_waitcnt lgkmcnt(0)" if P["no_vmwait"] else f"s_waitcnt vmcnt({vm}) lgkmcnt(0)"]
+        if not P["no_barrier"]:
+            post[BARRIER_AFTER] += ["s_barrier"]
+        for tn in range(7):  # W fragment tn is dead behind its row; its re-read also has to sit behind the barrier
+            post[max(8 * tn + 7, BARRIER_AFTER)] += rdW(tn, "n")
         for tm in range(8):
-            post[min(63, 56 + tm + XDELAY)] += rdX(tm, "n")
+            post[min(63, 56 + tm + P["xdelay"])] += rdX(tm, "n")
         post[63] += rdW(7, "n")
         pre[56].append("s_waitcnt lgkmcnt(14)")
     else:
         pre[56].append("s_waitcnt lgkmcnt(0)")
-    if dma:
+    if dma and not P["no_dma"]:
         for j, g in enumerate(dma_block("%[m0_c]", "%[k2]")):
-            post[DMA_FIRST - 1 + j * DMA_EVERY] += g
+            post[min(63, P["dma_first"] - 1 + j * P["dma_every"])] += g
+        if P["pf"]:
+            post[P["pf_at"]] += pf_group()
     out = []
     for i in range(64):
         out += pre[i]
-        out.append(mfma(i // 8, i % 8))
-        out += post[i]
+        if not P["no_mfma"]:
+            out.append(mfma(i // 8, i % 8))
+        out += [l for l in post[i] if not (P["no_reads"] and l.startswith("ds_read"))]
     if reads:
         out += swap_slots()
     if dma:
         out.append("s_add_u32 %[k2], %[k2], 0x80")
     return out
+
+
+def dump(rows):
+    """fragment rows `rows` (4 of them) of this wave's accumulators -> its quarter of the ring, fp32, swizzled chunks"""
+    L = []
+    for tn in range(8):
+        L += [f"v_xor_b32 v{120 + tn}, {tn * 64}, %[dkey]", f"v_add_u32 v{120 + tn}, %[drow], v{120 + tn}"]
+    for tm in rows:
+        for tn in range(8):
+            a = ACC(tn, tm)
+            L.append(f"ds_write_b128 v{120 + tn}, a[{a}:{a + 3}] offset:{(tm % 4) * 8192}")
+    L.append("s_waitcnt lgkmcnt(0)")
+    return L
 
 
 def zero_acc():
@@ -138,15 +198,18 @@ def pipelined():
     for g in dma_block("%[m0_n]", "%[k2]"):
         L += g
     L.append("s_add_u32 %[k2], %[k2], 0x80")
+    if P["pf"]:
+        L += pf_group()
     L += zero_acc()
-    L += ["s_waitcnt vmcnt(16)", "s_barrier"]
+    L += [f"s_waitcnt vmcnt({17 if P['pf'] else 16})", "s_barrier"]
     L += canonical_prologue_reads()
     L += ["s_cmp_eq_u32 %[nloop], 0", "s_cbranch_scc1 2f", "1:"]
     L += step(True, True)
     L += ["s_sub_u32 %[nloop], %[nloop], 1", "s_cmp_lg_u32 %[nloop], 0", "s_cbranch_scc1 1b", "2:"]
     L += step(False, True)
     L += step(False, False)
-    L += ["s_nop 7", "s_nop 7", "s_nop 7"]
+    L += ["s_nop 7", "s_nop 7", "s_nop 7", "s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]
+    L += dump(range(4))
     return L
 
 
@@ -187,7 +250,8 @@ def scrubbed():
     L += ["s_sub_u32 %[nloop], %[nloop], 1", "s_cmp_lg_u32 %[nloop], 0", "s_cbranch_scc1 1b", "2:"]
     L += scrub_step(False)
     L += scrub_step(False)
-    L += ["s_nop 7", "s_nop 7", "s_nop 7"]
+    L += ["s_nop 7", "s_nop 7", "s_nop 7", "s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]
+    L += dump(range(4))
     return L
 
 
@@ -196,42 +260,43 @@ def emit(name, lines, scrub):
     print("    asm volatile( \\")
     for l in lines:
         print(f'        "{l}\\n\\t" \\')
-    outs = ['[alo_c] "+v"(alo_c)', '[ahi_c] "+v"(ahi_c)', '[blo_c] "+v"(blo_c)', '[bhi_c] "+v"(bhi_c)',
+    outs = [f'"={{a[{32 * t}:{32 * t + 31}]}}"(acc{t})' for t in range(4, 8)]
+    outs += ['[alo_c] "+v"(alo_c)', '[ahi_c] "+v"(ahi_c)', '[blo_c] "+v"(blo_c)', '[bhi_c] "+v"(bhi_c)',
             '[alo_n] "+v"(alo_n)', '[ahi_n] "+v"(ahi_n)', '[blo_n] "+v"(blo_n)', '[bhi_n] "+v"(bhi_n)',
             '[k2] "+s"(k2)', '[m0_c] "+s"(m0_c)', '[m0_n] "+s"(m0_n)', '[nloop] "+s"(nloop)', '[t0] "=&s"(t0)']
     if scrub:
         outs += ['[vt0] "=&v"(vt0)', '[vt1] "=&v"(vt1)']
-    ins = ['[va0] "v"(va0)', '[vb0] "v"(vb0)', '[vscale] "v"(vscale)', '[ra] "s"(ra)', '[rb] "s"(rb)', '[sa] "s"(sa)', '[sb] "s"(sb)']
-    clob = [f'"v{i}"' for i in range(128, 256)] + [f'"a{i}"' for i in range(256)] + ['"scc"', '"memory"']
+    ins = ['[va0] "v"(va0)', '[vb0] "v"(vb0)', '[vscale] "v"(vscale)', '[ra] "s"(ra)', '[rb] "s"(rb)', '[sa] "s"(sa)', '[sb] "s"(sb)',
+           '[drow] "v"(drow)', '[dkey] "v"(dkey)', '[pfoff] "v"(pfoff)', '[rpf] "s"(rpf)', '[klast] "s"(klast)']
+    clob = [f'"v{i}"' for i in range(119, 256)] + [f'"a{i}"' for i in range(128)] + ['"scc"', '"memory"']
     print("        : " + ", ".join(outs) + " \\")
     print("        : " + ", ".join(ins) + " \\")
     print("        : " + ", ".join(clob) + ")")
     print()
 
 
-def emit_readers():
-    """read_acc_row<TM>: the 8 accumulator quads (tn = 0..7) of fragment row TM out of the AGPRs (register names must be literal)."""
-    print("template <int TM> FP8MI_DEVICE void read_acc_row(f32x4 (&r)[8]);")
-    for tm in range(8):
-        print(f"template <> FP8MI_DEVICE void read_acc_row<{tm}>(f32x4 (&r)[8])")
-        print("{")
-        print("    float f[32];")
-        for half in range(2):
-            lines, outs = [], []
-            for q in range(16):
-                idx = half * 16 + q
-                tn, j = idx // 4, idx % 4
-                lines.append(f"v_accvgpr_read_b32 %{q}, a{ACC(tn, tm) + j}")
-                outs.append(f'"=v"(f[{idx}])')
-            print('    asm volatile("' + "\\n\\t".join(lines) + '" : ' + ", ".join(outs) + ");")
-        print("    for (int tn = 0; tn < 8; ++tn) r[tn] = f32x4{f[4 * tn], f[4 * tn + 1], f[4 * tn + 2], f[4 * tn + 3]};")
-        print("}")
+def emit_dump_hi():
+    print("#define FP8MI_GEMM256_DUMP_HI() \\")
+    print("    asm volatile( \\")
+    for l in dump(range(4, 8)):
+        print(f'        "{l}\\n\\t" \\')
+    ins = [f'"{{a[{32 * t}:{32 * t + 31}]}}"(acc{t})' for t in range(4, 8)] + ['[drow] "v"(drow)', '[dkey] "v"(dkey)']
+    print("        : \\")
+    print("        : " + ", ".join(ins) + " \\")
+    print("        : " + ", ".join(f'"v{i}"' for i in range(120, 128)) + ', "memory")')
     print()
 
 
 if __name__ == "__main__":
     print("// GENERATED by csrc/gen/gen_gemm256_loop.py - do not edit; see that file for the schedule.")
-    print(f"// DMA_FIRST={DMA_FIRST} DMA_EVERY={DMA_EVERY} XDELAY={XDELAY} BARRIER_AFTER={BARRIER_AFTER}")
+    print(f"// product schedule: {PRODUCT}")
     emit("FP8MI_GEMM256_LOOP", pipelined(), False)
     emit("FP8MI_GEMM256_LOOP_SCRUB", scrubbed(), True)
-    emit_readers()
+    emit_dump_hi()
+    print("#ifdef FP8MI_DIAG  // schedule variants and timing-only ablations (libfp8mi_diag.so, kernel ids 80 + variant)")
+    for v, over in sorted(VARIANTS.items()):
+        P.clear(); P.update(PRODUCT); P.update(over)
+        print(f"// variant {v}: {over}")
+        emit(f"FP8MI_GEMM256_LOOP_V{v}", pipelined(), False)
+    print("#define FP8MI_GEMM256_VARIANTS " + " ".join(f"X({v})" for v in sorted(VARIANTS)))
+    print("#endif")

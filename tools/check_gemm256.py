@@ -7,8 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "fp8-mps-metal_amd"), os.path.join(ROOT, "oracle")]
 import fp8_mi355x_native as n, fp8_oracle as o, fp8_mi355x_lib as L
 dev = torch.device("cuda:0")
+KID = int(sys.argv[1]) if len(sys.argv) > 1 else L.KERNEL_GEMM_256W   # a schedule variant of the diagnostic library: 80 + variant
 worst = 0.0
-for (M, K, N) in ((256, 256, 256), (256, 384, 512), (512, 1024, 256), (768, 640, 1024), (256, 4096, 256)):
+for (M, K, N) in ((256, 256, 256), (256, 384, 512), (512, 1024, 256), (768, 640, 1024), (256, 4096, 256), (1024, 3072, 2048)):
     rng = np.random.default_rng(M + K + N)
     for nan in (False, True):
         A = rng.integers(0, 256, size=(M, K), dtype=np.uint8); B = rng.integers(0, 256, size=(N, K), dtype=np.uint8)
@@ -18,7 +19,7 @@ for (M, K, N) in ((256, 256, 256), (256, 384, 512), (512, 1024, 256), (768, 640,
         bias = rng.standard_normal(N).astype(np.float32)
         tA, tB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
         for od in (torch.float32, torch.bfloat16):
-            got = n.fp8_scaled_mm(tA, tB, torch.from_numpy(sa), torch.from_numpy(sb), bias=torch.from_numpy(bias).to(dev), out_dtype=od, kernel=L.KERNEL_GEMM_256W)
+            got = n.fp8_scaled_mm(tA, tB, torch.from_numpy(sa), torch.from_numpy(sb), bias=torch.from_numpy(bias).to(dev), out_dtype=od, kernel=KID)
             ref = n.fp8_scaled_mm(tA, tB, torch.from_numpy(sa), torch.from_numpy(sb), bias=torch.from_numpy(bias).to(dev), out_dtype=od, kernel=L.KERNEL_GEMM_256, split_k=1)
             torch.cuda.synchronize()
             same = torch.equal(got, ref)
@@ -33,4 +34,4 @@ for (M, K, N) in ((256, 256, 256), (256, 384, 512), (512, 1024, 256), (768, 640,
                 bad = np.argwhere(d > 0)
                 print("  first mismatches (m, n):", bad[:8].tolist(), " count", len(bad))
                 sys.exit(1)
-print(f"256W: all shapes ok (worst err/bound {worst:.2e})")
+print(f"256W (kernel id {KID}): all shapes ok (worst err/bound {worst:.2e})")
