@@ -545,14 +545,17 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
         const double t256 = (double)(((p.M + 255) / 256) * ((p.N + 255) / 256));
         const double t128 = (double)(((p.M + 127) / 128) * ((p.N + 127) / 128));
         const double t64 = (double)(((p.M + 127) / 128) * ((p.N + 63) / 64));
-        const double us256 = rounds(t256, cus, 0.75, 0.25) * (8.0 + 1.6 * nk);       // (a quarter-filled round of 256x256
+        // whole 256x256 tiles and K-steps run on the hand-scheduled one-wave-per-SIMD kernel (fp8mi_gemm256.hip): 8.5 + 1.35 nk per
+        // round (FLUX: 40.8 us per tile at nk = 24, in-kernel stamps) against 8 + 1.6 nk for the ring kernel
+        const bool w256 = fp8mi_gemm256_supported(p);
+        const double us256 = rounds(t256, cus, 0.75, 0.25) * (w256 ? 8.5 + 1.35 * nk : 8.0 + 1.6 * nk);  // (a quarter-filled round of 256x256
         const double us128 = rounds(t128, 2 * cus, 0.55, 0.45) * (5.5 + 0.87 * nk);  //  tiles still costs 0.8 of a full one)
         const double us64 = rounds(t64, cus, 0.6, 0.4) * (5.0 + 0.37 * nk);
         if (t64 <= cus / 2) {
             // few tiles: one per CU at most, split-K (launch<>) fills the rest of the chip when a workspace came along;
             // with few rows of A the tile is better spent on N
             variant = (p.M <= 64 && p.ws && p.split != 1) ? FP8MI_KERNEL_GEMM_64x128 : FP8MI_KERNEL_GEMM_128x64;
-        } else if (us256 <= us128 && us256 <= us64) variant = FP8MI_KERNEL_GEMM_256;
+        } else if (us256 <= us128 && us256 <= us64) variant = w256 ? FP8MI_KERNEL_GEMM_256W : FP8MI_KERNEL_GEMM_256;
         else if (us128 <= us64) variant = FP8MI_KERNEL_GEMM_128;
         else variant = FP8MI_KERNEL_GEMM_128x64;
     }
@@ -565,6 +568,7 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     case FP8MI_KERNEL_GEMM_128x64: return launch<128, 64, 32, 32, 3, 1, 0, 2, 4>(p, s);  // 3 x 48 KiB ring, 2 K-steps per stage
     case FP8MI_KERNEL_GEMM_256: return launch<256, 256, 128, 64, 2, 2, 0, 1, 4>(p, s);   // 2 x 64 KiB ring, staggered wave groups
     case FP8MI_KERNEL_GEMM_64x128: return launch<64, 128, 32, 32, 3, 1, 0, 2, 4>(p, s);  // 3 x 48 KiB ring, for M <= 64
+    case FP8MI_KERNEL_GEMM_256W: return fp8mi_launch_gemm256(p, 0, s);                   // (only chosen above when fp8mi_gemm256_supported)
 #ifdef FP8MI_DIAG  // schedule variants kept for A/B timing (diagnostic library only; same results): tools/ab_kernels.py
     case 30: return launch<256, 256, 128, 64, 2, 1, 0, 1, 4>(p, s);            // 256x256, fragment reads before the stage DMA
     case 31: return launch<128, 128, 64, 32, 2, 1, 0, 1, 4>(p, s);             // 128x128, same

@@ -36,10 +36,11 @@ constexpr int kDumpRow = 8 * 1024;     // one fragment row
 // per-tensor value), scale_b, bias along n, bias along m (transposed).  Each lane fetches its two entries of every table
 // at kernel entry (loads in flight under the K loop, uniform type switches out of the epilogue's inner loop) and writes
 // them to the LDS after the loop.
-constexpr int kTabBytes = 4 * 512;                       // per wave
+constexpr int kTabBytes = 4 * 512 + 16;                  // per wave: four 128-entry tables, then scale_result
 constexpr int kTabBase = kRing256 + kFlagBytes;
-struct TabRegs {
-    float sa[2], sb[2], bn[2], bm[2];
+struct TabRegs {       // as loaded: nothing here is USED before the K loop (a use would wait for the load in front of it)
+    float sa[2], sb[2], sr;
+    uint32_t bias[2];  // raw fp32 bits, or a zero-extended 16-bit pattern
 };
 
 FP8MI_DEVICE TabRegs load_tables(const MMParams &p, int64_t m_wave, int64_t n_wave, int lane)
@@ -50,105 +51,152 @@ FP8MI_DEVICE TabRegs load_tables(const MMParams &p, int64_t m_wave, int64_t n_wa
         const int i = lane + 64 * h;
         t.sa[h] = p.scale_a[p.sa_row ? m_wave + i : 0];
         t.sb[h] = p.scale_b[p.sb_row ? n_wave + i : 0];
-        t.bn[h] = 0.0f;
-        t.bm[h] = 0.0f;
+        t.bias[h] = 0u;
     }
+    t.sr = 1.0f;
+    if (p.scale_result) t.sr = p.scale_result[0];
     if (p.bias != nullptr) {
         const int64_t base = p.transposed ? m_wave : n_wave;
-        float b[2];
         if (p.bias_dtype == FP8MI_F32) {
-            b[0] = ((const float *)p.bias)[base + lane];
-            b[1] = ((const float *)p.bias)[base + lane + 64];
-        } else if (p.bias_dtype == FP8MI_BF16) {
-            b[0] = (float)((const __bf16 *)p.bias)[base + lane];
-            b[1] = (float)((const __bf16 *)p.bias)[base + lane + 64];
+            t.bias[0] = ((const uint32_t *)p.bias)[base + lane];
+            t.bias[1] = ((const uint32_t *)p.bias)[base + lane + 64];
         } else {
-            b[0] = (float)((const _Float16 *)p.bias)[base + lane];
-            b[1] = (float)((const _Float16 *)p.bias)[base + lane + 64];
+            t.bias[0] = ((const uint16_t *)p.bias)[base + lane];
+            t.bias[1] = ((const uint16_t *)p.bias)[base + lane + 64];
         }
-        if (p.transposed) { t.bm[0] = b[0]; t.bm[1] = b[1]; }
-        else { t.bn[0] = b[0]; t.bn[1] = b[1]; }
     }
     return t;
 }
 
-FP8MI_DEVICE void store_tables(const TabRegs &t, float *tab, int lane)
+FP8MI_DEVICE void store_tables(const MMParams &p, const TabRegs &t, float *tab, int lane)
 {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+        float b = 0.0f;
+        if (p.bias != nullptr) {
+            if (p.bias_dtype == FP8MI_F32) b = __builtin_bit_cast(float, t.bias[h]);
+            else if (p.bias_dtype == FP8MI_BF16) b = __builtin_bit_cast(float, t.bias[h] << 16);
+            else b = (float)__builtin_bit_cast(_Float16, (uint16_t)t.bias[h]);
+        }
         tab[lane + 64 * h] = t.sa[h];
         tab[128 + lane + 64 * h] = t.sb[h];
-        tab[256 + lane + 64 * h] = t.bn[h];
-        tab[384 + lane + 64 * h] = t.bm[h];
+        tab[256 + lane + 64 * h] = p.transposed ? 0.0f : b;
+        tab[384 + lane + 64 * h] = p.transposed ? b : 0.0f;
     }
+    tab[512] = t.sr;
 }
 
 // Fused epilogue of one HALF of the wave tile (fragment rows 4 half .. 4 half + 3, i.e. 64 rows x 128 columns), read back
-// ROW-WISE from the accumulator dump (gen_gemm256_loop.py): a lane takes the 16-byte chunk at position `pos` of row r,
-// which holds the columns 4 (pos ^ (r & 15)) .. + 3, so every global store instruction writes whole rows (512 B of fp32
-// per 32 lanes, 256 B of 16-bit) without a second trip through the LDS.  Returns the sum of everything read (NaN vote).
-template <int OUT, bool BIAS, bool TRANSPOSED>
-FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, float sr, const uint8_t *dump, const float *tab, int half, int64_t m_wave, int64_t n_wave,
-                                 int lane)
+// ROW-WISE from the accumulator dump (gen_gemm256_loop.py).  A lane takes the 32 bytes at pair position pp of row r: the
+// chunks at positions 2 pp and 2 pp + 1, which hold the column chunks 2 (pp ^ (r >> 1)) + (r & 1) and its neighbour - eight
+// consecutive columns after an exchange in odd rows - so every global store instruction writes whole rows (16 lanes x
+// 32 B of fp32 or x 16 B of 16-bit types) without a second trip through the LDS.  Four rows per instruction, four
+// instructions' LDS reads in flight at a time (one wave per SIMD: nothing else hides their latency).  TABLES = false
+// (per-tensor scales): the scale tables are not read per element.  Returns the sum of everything read (NaN vote).
+typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
+typedef __attribute__((address_space(3))) const float lds_cf32;
+typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
+typedef __attribute__((address_space(1))) uint8_t glb_u8;
+
+template <int OUT, bool BIAS, bool TRANSPOSED, bool TABLES>
+FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave, int64_t n_wave, int lane)
 {
     constexpr int kEsz = OUT == FP8MI_F32 ? 4 : 2;
-    const int pos = lane & 31, rsub = lane >> 5;   // two rows per instruction
+    constexpr int kBatch = 4;
+    const int pp = lane & 15, rsub = lane >> 4;
+    glb_u8 *gC = (glb_u8 *)p.C + (m_wave * p.ldc + n_wave) * kEsz;
+    const float sa_u = tab[0], sb_u = tab[128];   // per-tensor: every entry of the table is the scale
     f32x4 nan_sum = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 4
-    for (int it = 0; it < 32; ++it) {              // 64 rows, two at a time
-        const int rr = it * 2 + rsub;              // row inside the half: fragment row rr >> 4, row rr & 15
-        const int r = rr & 15;
-        const f32x4 q = *(const f32x4 *)(dump + (rr >> 4) * kDumpRow + r * 512 + pos * 16);
-        nan_sum += q;
-        const int col = (pos ^ r) * 4;             // this chunk's first column inside the wave tile
-        const int row = half * 64 + rr;
-        const float sa = tab[row];
-        const f32x4 sb4 = *(const f32x4 *)(tab + 128 + col);
-        const f32x4 bn4 = *(const f32x4 *)(tab + 256 + col);
-        const float bm = tab[384 + row];
-        float v[4];
+    // two batches per trip where registers allow: the LDS reads of the second are scheduled above the arithmetic of the first
+    constexpr int kUnroll = (TABLES || BIAS) ? 1 : 2;
+#pragma unroll kUnroll
+    for (int it0 = 0; it0 < 16; it0 += kBatch) {
+        f32x4 q0[kBatch], q1[kBatch], sb0[kBatch], sb1[kBatch], bn0[kBatch], bn1[kBatch];
+        float sa[kBatch], bm[kBatch];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float x = TRANSPOSED ? (q[j] * sb4[j]) * sa : (q[j] * sa) * sb4[j];
-            if (BIAS) x = x + (TRANSPOSED ? bm : bn4[j]);
-            v[j] = x * sr;                          // (sr = 1.0f when there is no scale_result: exact)
+        for (int b = 0; b < kBatch; ++b) {
+            const int rr = (it0 + b) * 4 + rsub, r = rr & 15;   // row inside the half: fragment row rr >> 4, row r
+            lds_cu8 *src = dump + (rr >> 4) * kDumpRow + r * 512 + pp * 32;
+            const int swap = (r & 1) * 16;                      // odd rows hold the pair's chunks exchanged: undo it in the address
+            q0[b] = *(lds_cf32x4 *)(src + swap);
+            q1[b] = *(lds_cf32x4 *)(src + (16 - swap));
+            const int col = (pp ^ (r >> 1)) * 8, row = half * 64 + rr;
+            if (TABLES) {
+                sa[b] = tab[row];
+                sb0[b] = *(lds_cf32x4 *)(tab + 128 + col);
+                sb1[b] = *(lds_cf32x4 *)(tab + 128 + col + 4);
+            }
+            if (BIAS && !TRANSPOSED) {
+                bn0[b] = *(lds_cf32x4 *)(tab + 256 + col);
+                bn1[b] = *(lds_cf32x4 *)(tab + 256 + col + 4);
+            }
+            if (BIAS && TRANSPOSED) bm[b] = tab[384 + row];
         }
-        uint8_t *dst = (uint8_t *)p.C + ((m_wave + row) * p.ldc + n_wave + col) * kEsz;
-        if (OUT == FP8MI_F32) {
-            __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, (f32x4 *)dst);
-        } else if (OUT == FP8MI_BF16) {
-            __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1], h2 = (__bf16)v[2], h3 = (__bf16)v[3];
-            __builtin_nontemporal_store(u32x2{(uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16),
-                                              (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16)},
-                                        (u32x2 *)dst);
-        } else {
-            _Float16 h0 = (_Float16)v[0], h1 = (_Float16)v[1], h2 = (_Float16)v[2], h3 = (_Float16)v[3];
-            __builtin_nontemporal_store(u32x2{(uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16),
-                                              (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16)},
-                                        (u32x2 *)dst);
+#pragma unroll
+        for (int b = 0; b < kBatch; ++b) {
+            const int rr = (it0 + b) * 4 + rsub, r = rr & 15;
+            const int col = (pp ^ (r >> 1)) * 8, row = half * 64 + rr;
+            nan_sum += q0[b] + q1[b];
+            const f32x4 lo = q0[b], hi = q1[b];
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float a = j < 4 ? lo[j & 3] : hi[j & 3];
+                const float s_a = TABLES ? sa[b] : sa_u;
+                const float s_b = TABLES ? (j < 4 ? sb0[b][j & 3] : sb1[b][j & 3]) : sb_u;
+                float x = TRANSPOSED ? (a * s_b) * s_a : (a * s_a) * s_b;
+                if (BIAS) x = x + (TRANSPOSED ? bm[b] : (j < 4 ? bn0[b][j & 3] : bn1[b][j & 3]));
+                v[j] = x * sr;                                  // (sr = 1.0f when there is no scale_result: exact)
+            }
+            glb_u8 *dst = gC + ((int64_t)row * p.ldc + col) * kEsz;
+            if (OUT == FP8MI_F32) {
+                __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, (__attribute__((address_space(1))) f32x4 *)dst);
+                __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, (__attribute__((address_space(1))) f32x4 *)(dst + 16));
+            } else {
+                uint32_t w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {   // one packed convert (round to nearest even) per output pair
+                    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                    const f32x2_t pr = {v[2 * j], v[2 * j + 1]};
+                    if (OUT == FP8MI_BF16) {
+                        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                        w[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, bf16x2_t));
+                    } else {
+                        typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+                        w[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, f16x2_t));
+                    }
+                }
+                __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, (__attribute__((address_space(1))) u32x4 *)dst);
+            }
         }
     }
     return nan_sum;
 }
 
-template <int OUT>
-FP8MI_DEVICE f32x4 epilogue_half_flags(const MMParams &p, float sr, const uint8_t *dump, const float *tab, int half, int64_t m_wave,
+template <int OUT, bool TABLES>
+FP8MI_DEVICE f32x4 epilogue_half_flags(const MMParams &p, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave,
                                        int64_t n_wave, int lane)
 {
     if (p.bias == nullptr) {
-        if (p.transposed) return epilogue_half<OUT, false, true>(p, sr, dump, tab, half, m_wave, n_wave, lane);
-        return epilogue_half<OUT, false, false>(p, sr, dump, tab, half, m_wave, n_wave, lane);
+        if (p.transposed) return epilogue_half<OUT, false, true, TABLES>(p, sr, dump, tab, half, m_wave, n_wave, lane);
+        return epilogue_half<OUT, false, false, TABLES>(p, sr, dump, tab, half, m_wave, n_wave, lane);
     }
-    if (p.transposed) return epilogue_half<OUT, true, true>(p, sr, dump, tab, half, m_wave, n_wave, lane);
-    return epilogue_half<OUT, true, false>(p, sr, dump, tab, half, m_wave, n_wave, lane);
+    if (p.transposed) return epilogue_half<OUT, true, true, TABLES>(p, sr, dump, tab, half, m_wave, n_wave, lane);
+    return epilogue_half<OUT, true, false, TABLES>(p, sr, dump, tab, half, m_wave, n_wave, lane);
 }
 
-FP8MI_DEVICE f32x4 epilogue_half_any(const MMParams &p, float sr, const uint8_t *dump, const float *tab, int half, int64_t m_wave,
+FP8MI_DEVICE f32x4 epilogue_half_any(const MMParams &p, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave,
                                      int64_t n_wave, int lane)
 {
-    if (p.out_dtype == FP8MI_F32) return epilogue_half_flags<FP8MI_F32>(p, sr, dump, tab, half, m_wave, n_wave, lane);
-    if (p.out_dtype == FP8MI_BF16) return epilogue_half_flags<FP8MI_BF16>(p, sr, dump, tab, half, m_wave, n_wave, lane);
-    return epilogue_half_flags<FP8MI_F16>(p, sr, dump, tab, half, m_wave, n_wave, lane);
+    const bool tables = p.sa_row || p.sb_row;
+    if (p.out_dtype == FP8MI_F32)
+        return tables ? epilogue_half_flags<FP8MI_F32, true>(p, sr, dump, tab, half, m_wave, n_wave, lane)
+                      : epilogue_half_flags<FP8MI_F32, false>(p, sr, dump, tab, half, m_wave, n_wave, lane);
+    if (p.out_dtype == FP8MI_BF16)
+        return tables ? epilogue_half_flags<FP8MI_BF16, true>(p, sr, dump, tab, half, m_wave, n_wave, lane)
+                      : epilogue_half_flags<FP8MI_BF16, false>(p, sr, dump, tab, half, m_wave, n_wave, lane);
+    return tables ? epilogue_half_flags<FP8MI_F16, true>(p, sr, dump, tab, half, m_wave, n_wave, lane)
+                  : epilogue_half_flags<FP8MI_F16, false>(p, sr, dump, tab, half, m_wave, n_wave, lane);
 }
 
 #ifdef FP8MI_STAMP  // diagnostic build only: phase stamps of wave 0 of every workgroup (tools/stamp_gemm256.py)
@@ -172,17 +220,15 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
     STAMP256(0);
     const MMParams p = pin_params(p_in);
     FP8MI_PIN_S(tiles_m); FP8MI_PIN_S(tiles_n); FP8MI_PIN_S(nwg);
-    const float sr_v = p.scale_result ? p.scale_result[0] : 1.0f;   // in flight under the K loop
     __shared__ __attribute__((aligned(16))) uint8_t smem[kRing256 + kFlagBytes + 4 * kTabBytes];
     if (threadIdx.x == 0) *(__attribute__((address_space(3))) volatile int *)(lds_void *)(smem + kRing256) = 0;  // NaN verdict word (ordered by the K loop's barriers)
 
     int tile_m, tile_n, kslice, wg;
     tile_of_block(blockIdx.x, nwg, tiles_m, tiles_n, tile_m, tile_n, kslice, wg);
     const int64_t m0 = (int64_t)tile_m * kBM, n0 = (int64_t)tile_n * kBN;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    FP8MI_PIN_S(wave);   // (opaque: else hipcc keeps threadIdx.x alive - in scratch - to re-derive it inside the pass loop)
     const int wm0 = (wave & 1) * 128, wn0 = (wave >> 1) * 128;
-    const TabRegs tabs = load_tables(p, m0 + wm0, n0 + wn0, lane);   // in flight under the K loop
 
     // raw buffer descriptors (stride 0, range-checked) rebased to this tile's first row; whole tiles only
     const uint64_t pa = (uint64_t)(p.A + m0 * p.lda), pb = (uint64_t)(p.B + n0 * p.ldb);
@@ -194,7 +240,7 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
     rb[0] = __builtin_amdgcn_readfirstlane(rb[0]); rb[1] = __builtin_amdgcn_readfirstlane(rb[1]);
     rb[2] = __builtin_amdgcn_readfirstlane(rb[2]);
 
-    const uint32_t sa = (uint32_t)__builtin_amdgcn_readfirstlane((int)(32 * p.lda)), sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(32 * p.ldb));
+    const uint32_t sa = (uint32_t)(32 * p.lda), sb = (uint32_t)(32 * p.ldb);   // byte stride between a wave's consecutive row groups
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void *)smem;
     const uint32_t vscale = (uint32_t)kScaleOne;
     const int nk = (int)(p.K / BK);  // >= 2 (host)
@@ -212,6 +258,7 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
         //  them in scratch across the epilogue)
         int lane_l;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_l));
+        const TabRegs tabs = load_tables(p, m0 + wm0, n0 + wn0, lane_l);   // in flight under the K loop, stored to the LDS behind it
         // staging plan (fp8mi_gemm.hip): wave w stages the 1-KiB groups w, w + 4, ... of both operands; lane -> (row, swizzled chunk)
         const int row0 = wave * 8 + (lane_l >> 3);
         const int chunk = (lane_l & 7) ^ (((wave & 1) * 4 + (lane_l >> 4)) & 7);
@@ -223,7 +270,7 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
         uint32_t blo_c = lds0 + kBM * BK + wn0 * BK + off1, bhi_c = lds0 + kBM * BK + wn0 * BK + off2;
         uint32_t alo_n = alo_c + kSlotBytes, ahi_n = ahi_c + kSlotBytes, blo_n = blo_c + kSlotBytes, bhi_n = bhi_c + kSlotBytes;
         uint32_t m0_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + wave * 1024)), m0_n = m0_c + kSlotBytes;
-        uint32_t k2 = 0, nloop = (uint32_t)(nk - 2), t0;
+        uint32_t k2 = 0, nloop = (uint32_t)(nk - 2), t0, t1;
         // L2 prefetch (gen_gemm256_loop.py pf_group): the 32 tiles an XCD runs at one time are 4 m-tiles x 8 n-tiles of one group
         // (tile_of_block), so an A panel has 8 readers and a B panel 4; each warms its share of the lines of a later stage:
         // wave 0 rows 64 (tile_m & 3) .. + 63 of its B panel, wave 1 rows 32 (tile_n & 7) .. + 31 of its A panel (other lanes
@@ -249,15 +296,16 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
             FP8MI_GEMM256_LOOP_SCRUB();
             (void)vt0; (void)vt1;
         }
-        (void)t0;
+        (void)t0; (void)t1;
         if (pass == 0) STAMP256(2);
         int lane_e;
         int64_t m_wave = m0 + wm0, n_wave = n0 + wn0;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e), "+s"(m_wave), "+s"(n_wave));
-        const uint8_t *dump = smem + wave * kDumpWave;
-        float *tab = (float *)(smem + kTabBase + wave * kTabBytes);
-        if (pass == 0) store_tables(tabs, tab, lane_e);
-        const float sr = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sr_v)));
+        lds_cu8 *dump = (lds_cu8 *)(lds_void *)(smem + wave * kDumpWave);
+        float *tabw = (float *)(smem + kTabBase + wave * kTabBytes);
+        store_tables(p, tabs, tabw, lane_e);
+        lds_cf32 *tab = (lds_cf32 *)(lds_void *)tabw;
+        const float sr = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tabw[512])));
         f32x4 t = epilogue_half_any(p, sr, dump, tab, 0, m_wave, n_wave, lane_e);
         if (pass == 0) STAMP256(3);
         FP8MI_GEMM256_DUMP_HI();

@@ -39,6 +39,7 @@ PRODUCT = dict(
     dma_every=3,      # MFMAs between DMA instructions
     xdelay=1,         # X fragment tm is re-read this many MFMAs after MFMA(7, tm)
     barrier_after=7,  # the step's barrier sits behind this MFMA index
+    schedule=1,       # 1: DMA under MFMAs dma_first.. of the step, one barrier; 2: DMA as an even stream, two barriers (see step2)
     pf=2,             # > 0: each step one L2 prefetch instruction per wave for the stage `pf` steps ahead of the DMA's (see pf_group)
     pf_at=56,         # index of the MFMA after which it is issued (behind the step's last DMA)
     # timing-only ablations (wrong results): which parts of the steady-state step are left out
@@ -61,6 +62,8 @@ VARIANTS = {
     14: dict(barrier_after=3, dma_first=4),
     15: dict(pf=4),
     16: dict(pf_at=20),
+    17: dict(schedule=2),
+    18: dict(schedule=2, xdelay=0),
 }
 P = dict(PRODUCT)
 
@@ -113,15 +116,15 @@ def pf_group():
     """L2 prefetch: one dword per 128-byte line of this wave's share of a later stage (the tiles that run on one XCD at one
     time share A and B panels; each warms 1/8 of its A and 1/4 of its B panel - fp8mi_gemm256.hip sets up the offsets).
     The data is discarded; the load is younger than the step's DMAs, so the counted vmcnt wait lets it stay in flight."""
-    return [f"s_add_u32 %[t0], %[k2], {hex(128 * P['pf'])}", "s_min_u32 %[t0], %[t0], %[klast]",
-            "buffer_load_dword v119, %[pfoff], %[rpf], %[t0] offen"]
+    return [f"s_add_u32 %[t1], %[k2], {hex(128 * P['pf'])}", "s_min_u32 %[t1], %[t1], %[klast]",
+            "buffer_load_dword v119, %[pfoff], %[rpf], %[t1] offen"]
 
 
 def swap_slots():
     out = []
     for r in ("alo", "ahi", "blo", "bhi"):
         out.append(f"v_swap_b32 %[{r}_c], %[{r}_n]")
-    out += ["s_mov_b32 %[t0], %[m0_c]", "s_mov_b32 %[m0_c], %[m0_n]", "s_mov_b32 %[m0_n], %[t0]"]
+    out += ["s_mov_b32 %[t1], %[m0_c]", "s_mov_b32 %[m0_c], %[m0_n]", "s_mov_b32 %[m0_n], %[t1]"]
     return out
 
 
@@ -182,6 +185,88 @@ def dump(rows):
             a = ACC(tn, tm)
             L.append(f"ds_write_b128 v{120 + tn}, a[{a}:{a + 3}] offset:{(tm % 4) * 8192}")
     L.append("s_waitcnt lgkmcnt(0)")
+    return L
+
+
+# ---- schedule 2: the stage DMA as ONE even stream over the whole step, two barriers -------------------------------------
+# The address path of a CU takes ~28 cycles per 1-KiB DMA instruction (profiles/r02_pmc_gemm_flux.txt): 64 of them per K-step
+# need ~1800 cycles, more than the 46 MFMAs (1472 cycles) schedule 1 issues them under - it stalls ~320 cycles per step
+# in the issue (ablation: profiles/r02_gemm256_variants.txt).  Here a stage is issued B panel first, then A panel, one
+# instruction every 4 MFMAs: 8, 12, .. 60 of this step and 0, 4 of the next (m0 and the offset register simply carry over).
+# That works because the two panels have different deadlines: the W fragments (B) of stage t+1 are re-read from row 0 on,
+# the X fragments (A) only in row 7.  Barrier 1 (behind MFMA 7): every wave is done reading stage t -> its slot may be
+# refilled; B of stage t+1 has landed (vmcnt 9: the A instructions and the prefetch issued since may stay in flight).
+# Barrier 2 (behind MFMA 55): A of stage t+1 has landed (vmcnt 12: the 8 B and 4 A instructions of stage t+2 issued since).
+def dma_group2(j, slot_m0, kreg):
+    """instruction j = 0..15 of a stage's stream: 0..7 B panel (LDS groups 32 + w + 4 jo), 8..15 A panel"""
+    g = []
+    if j == 0:
+        g += [f"s_add_u32 m0, {slot_m0}, 0x8000", f"s_mov_b32 %[t0], {kreg}"]
+    elif j == 8:
+        g += [f"s_sub_u32 m0, m0, {hex(0x8000 + 7 * 0x1000)}", "s_mul_i32 %[t1], %[sb], 7", "s_sub_u32 %[t0], %[t0], %[t1]"]
+    else:
+        g += ["s_add_u32 m0, m0, 0x1000", f"s_add_u32 %[t0], %[t0], {'%[sb]' if j < 8 else '%[sa]'}"]
+    g += ["s_nop 0"]
+    g += ["buffer_load_dwordx4 %[vb0], %[rb], %[t0] offen lds" if j < 8 else "buffer_load_dwordx4 %[va0], %[ra], %[t0] offen lds"]
+    return g
+
+
+def step2(dma, reads, pf=True):
+    pre = [[] for _ in range(64)]
+    post = [[] for _ in range(64)]
+    for tm in range(8):
+        pre[tm].append(f"s_waitcnt lgkmcnt({min(15, 2 * (7 - tm) + 2)})")
+    if reads:
+        # the stream of stage t+1 ends here (its A-panel instructions 14, 15); m0 / t0 carry over from the previous step
+        post[0] += dma_group2(14, None, None)
+        post[4] += dma_group2(15, None, None)
+        post[7] += ["s_waitcnt vmcnt(9) lgkmcnt(0)", "s_barrier"]
+        for tn in range(7):
+            post[8 * tn + 7] += rdW(tn, "n")
+        post[55] += [f"s_waitcnt vmcnt({12 if dma else 0})", "s_barrier"]
+        for tm in range(8):
+            post[min(63, 56 + tm + P["xdelay"])] += rdX(tm, "n")
+        post[63] += rdW(7, "n")
+        pre[56].append("s_waitcnt lgkmcnt(14)")
+    else:
+        pre[56].append("s_waitcnt lgkmcnt(0)")
+    if dma:
+        for j in range(14):
+            post[8 + 4 * j] += dma_group2(j, "%[m0_c]", "%[k2]")
+        if P["pf"] and pf:
+            post[62] += pf_group()
+    out = []
+    for i in range(64):
+        out += pre[i]
+        out.append(mfma(i // 8, i % 8))
+        out += post[i]
+    if reads:
+        out += swap_slots()
+    if dma:
+        out.append("s_add_u32 %[k2], %[k2], 0x80")
+    return out
+
+
+def pipelined2():
+    L = []
+    for j in range(16):   # stage 0, whole
+        L += dma_group2(j, "%[m0_c]", "%[k2]")
+    L.append("s_add_u32 %[k2], %[k2], 0x80")
+    for j in range(14):   # stage 1 up to the two instructions the first step issues
+        L += dma_group2(j, "%[m0_n]", "%[k2]")
+    L.append("s_add_u32 %[k2], %[k2], 0x80")
+    if P["pf"]:
+        L += pf_group()
+    L += zero_acc()
+    L += [f"s_waitcnt vmcnt({14 + (1 if P['pf'] else 0)})", "s_barrier"]
+    L += canonical_prologue_reads()
+    L += ["s_cmp_eq_u32 %[nloop], 0", "s_cbranch_scc1 2f", "1:"]
+    L += step2(True, True)
+    L += ["s_sub_u32 %[nloop], %[nloop], 1", "s_cmp_lg_u32 %[nloop], 0", "s_cbranch_scc1 1b", "2:"]
+    L += step2(False, True)
+    L += step2(False, False)
+    L += ["s_nop 7", "s_nop 7", "s_nop 7", "s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]
+    L += dump(range(4))
     return L
 
 
@@ -263,7 +348,7 @@ def emit(name, lines, scrub):
     outs = [f'"={{a[{32 * t}:{32 * t + 31}]}}"(acc{t})' for t in range(4, 8)]
     outs += ['[alo_c] "+v"(alo_c)', '[ahi_c] "+v"(ahi_c)', '[blo_c] "+v"(blo_c)', '[bhi_c] "+v"(bhi_c)',
             '[alo_n] "+v"(alo_n)', '[ahi_n] "+v"(ahi_n)', '[blo_n] "+v"(blo_n)', '[bhi_n] "+v"(bhi_n)',
-            '[k2] "+s"(k2)', '[m0_c] "+s"(m0_c)', '[m0_n] "+s"(m0_n)', '[nloop] "+s"(nloop)', '[t0] "=&s"(t0)']
+            '[k2] "+s"(k2)', '[m0_c] "+s"(m0_c)', '[m0_n] "+s"(m0_n)', '[nloop] "+s"(nloop)', '[t0] "=&s"(t0)', '[t1] "=&s"(t1)']
     if scrub:
         outs += ['[vt0] "=&v"(vt0)', '[vt1] "=&v"(vt1)']
     ins = ['[va0] "v"(va0)', '[vb0] "v"(vb0)', '[vscale] "v"(vscale)', '[ra] "s"(ra)', '[rb] "s"(rb)', '[sa] "s"(sa)', '[sb] "s"(sb)',
@@ -290,13 +375,13 @@ def emit_dump_hi():
 if __name__ == "__main__":
     print("// GENERATED by csrc/gen/gen_gemm256_loop.py - do not edit; see that file for the schedule.")
     print(f"// product schedule: {PRODUCT}")
-    emit("FP8MI_GEMM256_LOOP", pipelined(), False)
+    emit("FP8MI_GEMM256_LOOP", pipelined2() if P["schedule"] == 2 else pipelined(), False)
     emit("FP8MI_GEMM256_LOOP_SCRUB", scrubbed(), True)
     emit_dump_hi()
     print("#ifdef FP8MI_DIAG  // schedule variants and timing-only ablations (libfp8mi_diag.so, kernel ids 80 + variant)")
     for v, over in sorted(VARIANTS.items()):
         P.clear(); P.update(PRODUCT); P.update(over)
         print(f"// variant {v}: {over}")
-        emit(f"FP8MI_GEMM256_LOOP_V{v}", pipelined(), False)
+        emit(f"FP8MI_GEMM256_LOOP_V{v}", pipelined2() if P["schedule"] == 2 else pipelined(), False)
     print("#define FP8MI_GEMM256_VARIANTS " + " ".join(f"X({v})" for v in sorted(VARIANTS)))
     print("#endif")

@@ -52,7 +52,7 @@ def clean_bytes(rng, shape):
 
 
 def uses_mfma(kernel, M, K):
-    if kernel in TILE_KERNELS or kernel in (L.KERNEL_SKINNY, L.KERNEL_GEMV_MX):
+    if kernel in TILE_KERNELS or kernel in (L.KERNEL_SKINNY, L.KERNEL_GEMV_MX, L.KERNEL_GEMM_256W):
         return True
     if M == 1 and kernel in (L.KERNEL_AUTO, L.KERNEL_GEMV):
         return K % 16 == 0 and K > 4096   # the vec-mat hands deep K to the matrix core; K <= 4096 (config C1) stays fp32 FMA
@@ -565,6 +565,91 @@ def test_fused_epilogue(native, cuda, oracle, out_dtype, M):
     exact = oracle.scaled_mm(A, B, [0.01], [0.02], accumulate="f64") + bb.float().numpy()[None, :]
     bound = oracle.abs_dot_bound(A, B, [0.01], [0.02]) + np.abs(bb.float().numpy())[None, :]
     assert np.all(np.abs(got - exact) <= (MFMA_TOL if M > 1 else MM_TOL) * bound + 1e-30)
+
+
+# ---------------------------------------------------------------------------
+# 256x256 tile, one wave per SIMD, hand-scheduled K loop (FP8MI_KERNEL_GEMM_256W)
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("M,K,N", [(256, 256, 256), (256, 384, 512), (512, 1024, 256), (768, 640, 1024), (256, 4096, 256)])
+def test_gemm256w_parity_and_bits_of_the_ring_kernel(native, cuda, oracle, M, K, N):
+    """The generated-assembly loop keeps the ring kernels' LDS image, fragment -> MFMA operand map and K order, so its
+    result must equal the unsplit ring kernel's BIT FOR BIT (what makes a sharded linear equal the unsharded one does
+    not depend on which tile kernel a shape lands on) and the oracle's within the matrix-core tolerance; every epilogue
+    form, both loop variants (the NaN redo runs the scrubbing loop) and K down to the two-step minimum."""
+    rng = np.random.default_rng(M + K + N)
+    A = clean_bytes(rng, (M, K))
+    B = clean_bytes(rng, (N, K))
+    sa = rng.uniform(0.005, 0.02, size=M).astype(np.float32)
+    sb = rng.uniform(0.005, 0.02, size=N).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    tA, tB = dev(A, cuda), dev(B, cuda)
+
+    def both(**kw):
+        a = native.fp8_scaled_mm(tA, tB, kernel=L.KERNEL_GEMM_256W, **kw)
+        b = native.fp8_scaled_mm(tA, tB, kernel=L.KERNEL_GEMM_256, split_k=1, **kw)
+        assert torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(), b.nan_to_num()), kw.keys()
+        return a
+
+    check_mm(oracle, native, cuda, A, B, [0.01], [0.02], kernel=L.KERNEL_GEMM_256W)
+    check_mm(oracle, native, cuda, A, B, sa, sb, kernel=L.KERNEL_GEMM_256W, bias=bias, scale_result=0.25)
+    check_mm(oracle, native, cuda, A, B, sa, [0.02], kernel=L.KERNEL_GEMM_256W, bias=bias, out_dtype=torch.bfloat16)
+    check_mm(oracle, native, cuda, A, B, [0.01], sb, kernel=L.KERNEL_GEMM_256W, out_dtype=torch.float16)
+    s1, sN, sM = torch.full((1,), 0.01), dev(sb, cuda), dev(sa, cuda)
+    for od in (torch.float32, torch.bfloat16, torch.float16):
+        both(scale_a=s1, scale_b=s1, out_dtype=od)
+        both(scale_a=sM, scale_b=sN, out_dtype=od, bias=dev(bias, cuda))
+        both(scale_a=s1, scale_b=sN, out_dtype=od, bias=dev(bias, cuda, torch.bfloat16), scale_result=torch.full((1,), 0.5))
+        both(scale_a=sM, scale_b=s1, out_dtype=od, bias=dev(bias, cuda, torch.float16))
+    # transposed epilogue (bias per row of this call, scales in the swapped order)
+    bias_m = rng.standard_normal(M).astype(np.float32)
+    both(scale_a=sM, scale_b=sN, bias=dev(bias_m, cuda), transposed_epilogue=True)
+    both(scale_a=s1, scale_b=s1, transposed_epilogue=True, out_dtype=torch.bfloat16)
+    # NaN bytes: reference semantics (decode to 0: the tile is redone with the scrubbing loop) and OCP propagation
+    A[3, 17] = 0x7F
+    B[N - 1, K - 1] = 0xFF
+    tA, tB = dev(A, cuda), dev(B, cuda)
+    check_mm(oracle, native, cuda, A, B, sa, sb, kernel=L.KERNEL_GEMM_256W, bias=bias)
+    both(scale_a=sM, scale_b=sN, bias=dev(bias, cuda), out_dtype=torch.bfloat16)
+    got = both(scale_a=s1, scale_b=s1, nan_mode=L.NAN_PROPAGATE).cpu().numpy()
+    nan = np.isnan(got)
+    assert nan[3, :].all() and nan[:, N - 1].all() and nan.sum() == N + M - 1
+
+
+def test_gemm256w_envelope_dispatch_and_exactness(native, cuda, oracle):
+    """Outside whole tiles / K-steps the explicit id refuses and AUTO falls back to the ring kernels; inside, AUTO picks it
+    for large shapes (same bits either way); operands within a 2^12 product range are summed exactly by the matrix core,
+    so a wrong register or LDS address in the generated loop cannot hide behind the hardware tolerance; a padded row
+    stride (lda, ldb, ldc > the row length) goes through the descriptors and the epilogue untouched."""
+    z = torch.zeros
+    for (M, K, N) in ((255, 256, 256), (256, 256, 300), (256, 128, 256), (256, 272, 256)):
+        with pytest.raises(RuntimeError):
+            native.fp8_scaled_mm(z(M, K, dtype=torch.uint8, device=cuda), z(N, K, dtype=torch.uint8, device=cuda), torch.ones(1),
+                                 torch.ones(1), kernel=L.KERNEL_GEMM_256W)
+    with pytest.raises(RuntimeError):   # a forced K split belongs to the ring kernels
+        native.fp8_scaled_mm(z(256, 4096, dtype=torch.uint8, device=cuda), z(256, 4096, dtype=torch.uint8, device=cuda), torch.ones(1),
+                             torch.ones(1), kernel=L.KERNEL_GEMM_256W, split_k=2)
+    rng = np.random.default_rng(79)
+    A = (0x28 + rng.integers(0, 0x20, size=(512, 1024))).astype(np.uint8)
+    B = (0x28 + rng.integers(0, 0x20, size=(768, 1024))).astype(np.uint8)
+    check_mm(oracle, native, cuda, A, B, [0.5], [2.0], kernel=L.KERNEL_GEMM_256W, tol=MM_TOL)
+    # AUTO on a large shape of whole tiles: the same bits as the explicit id and as the ring kernel
+    g = torch.Generator(device=cuda).manual_seed(5)
+    a = torch.randint(0, 0x7F, (2048, 1024), dtype=torch.uint8, device=cuda, generator=g)
+    b = torch.randint(0, 0x7F, (4096, 1024), dtype=torch.uint8, device=cuda, generator=g)
+    s = torch.full((1,), 0.01)
+    r_auto = native.fp8_scaled_mm(a, b, s, s, out_dtype=torch.bfloat16)
+    r_w = native.fp8_scaled_mm(a, b, s, s, out_dtype=torch.bfloat16, kernel=L.KERNEL_GEMM_256W)
+    r_ring = native.fp8_scaled_mm(a, b, s, s, out_dtype=torch.bfloat16, kernel=L.KERNEL_GEMM_256, split_k=1)
+    assert torch.equal(r_auto, r_w) and torch.equal(r_w, r_ring)
+    # padded strides
+    bufA = torch.randint(0, 0x7F, (256, 640), dtype=torch.uint8, device=cuda, generator=g)
+    bufB = torch.randint(0, 0x7F, (512, 768), dtype=torch.uint8, device=cuda, generator=g)
+    out = torch.full((256, 1024), -7.0, dtype=torch.float32, device=cuda)
+    va, vb, vo = bufA[:, :512], bufB[:, :512], out[:, :512]
+    native.fp8_scaled_mm(va, vb, s, s, kernel=L.KERNEL_GEMM_256W, out=vo)
+    ref = native.fp8_scaled_mm(va.contiguous(), vb.contiguous(), s, s, kernel=L.KERNEL_GEMM_256, split_k=1)
+    assert torch.equal(vo, ref) and bool((out[:, 512:] == -7.0).all())
 
 
 @pytest.mark.parametrize("kernel", TILE_KERNELS)

@@ -5,7 +5,7 @@ outside ALLOW_SCRATCH has a private segment.   python tools/check_spills.py [fil
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "fp8-mps-metal_amd", "csrc")
-files = sys.argv[1:] or ["fp8mi_gemm.hip", "fp8mi_gemv.hip", "fp8mi_skinny.hip", "fp8mi_cast.hip", "fp8mi_generic.hip"]
+files = sys.argv[1:] or ["fp8mi_gemm.hip", "fp8mi_gemm256.hip", "fp8mi_gemv.hip", "fp8mi_skinny.hip", "fp8mi_cast.hip", "fp8mi_generic.hip"]
 # The 256x256 kernel sits AT the 256-register limit (128 accumulators + 96 fragment registers + addressing at two waves per
 # SIMD) and its allocation is fragile: unrelated edits (factoring the DMA issue into a helper, carrying two fewer lane
 # constants) moved it from 0 to 2 and to 26 spilled VGPRs.  The shipped form has none; keep it that way - check after every edit.
@@ -24,5 +24,12 @@ with tempfile.TemporaryDirectory() as td:
             flag = "  <-- SCRATCH" if over else ("  (tolerated, outside the K loop)" if vspill else "")
             print(f"{f:20s} vgpr {vgpr:3d}  vgpr_spill {vspill:3d}  sgpr_spill {sspill:3d}  scratch {priv:4d}  {short}{flag}")
             bad += 1 if over else 0
+        if f == "fp8mi_gemm256.hip":
+            # its accumulators live in a[0:255] by hand (csrc/gen/gen_gemm256_loop.py); the only AGPR instructions allowed are
+            # the generator's: MFMAs, `v_accvgpr_write_b32 aN, 0` and `ds_write_b128 ..., a[..]`.  Anything else means hipcc
+            # parked or moved values in AGPRs around the hand-written loop.
+            n = len(re.findall(r"v_accvgpr_read|v_accvgpr_mov|v_accvgpr_write_b32 a\d+, [vs]", asm))
+            print(f"{f:20s} compiler-generated AGPR traffic: {n} instruction(s){'  <-- AGPR' if n else ''}")
+            bad += 1 if n else 0
 print(f"{bad} kernel(s) spill beyond what is tolerated")
 sys.exit(1 if bad else 0)
