@@ -34,5 +34,5 @@ for p in "${passes[@]}"; do
   timeout -k 10 200 rocprofv3 --pmc $p --output-format csv -d "$O/p$i" -o p -- python tools/run_workload.py "$w" 6 "$kid" > "$O/p$i.log" 2>&1 || { echo "pass $i failed: $p"; tail -3 "$O/p$i.log"; }
   i=$((i+1))
 done
-python tools/summarize_prof.py "$O" gemm_kernel > "$O/summary.txt"
+python tools/summarize_prof.py "$O" gemm > "$O/summary.txt"   # gemm_kernel<...> (ring) or gemm256_kernel<0>
 cat "$O/summary.txt"

@@ -24,10 +24,10 @@ for w in ("gemm", "gemv", "gemv_sq", "flux", "skinny", "decode", "quantize", "qu
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             # the workload's own kernel only (the synthetic-data generator also runs amax / encode kernels)
-            want = {"gemm": "gemm_kernel", "flux": "gemm_kernel", "decode": "gemm_kernel", "gemv": "gemv_kernel", "gemv_sq": "gemv_kernel",
-                    "skinny": "skinny_kernel", "quantize": "encode_kernel<0, 0, false>", "quantize_rne": "encode_kernel<0, 1, false>",
-                    "dequant": "dequant_kernel"}[w]
-            if want in r["Kernel_Name"]:
+            want = {"gemm": ("gemm_kernel",), "flux": ("gemm256_kernel", "gemm_kernel"), "decode": ("gemm_kernel",), "gemv": ("gemv_kernel",),
+                    "gemv_sq": ("gemv_kernel",), "skinny": ("gemv_mx_kernel", "skinny_kernel"), "quantize": ("encode_kernel<0, 0, false>",),
+                    "quantize_rne": ("encode_kernel<0, 1, false>",), "dequant": ("dequant_kernel",)}[w]
+            if any(x in r["Kernel_Name"] for x in want):
                 agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
         k, v = max(agg.items(), key=lambda kv: len(kv[1]))
         vals[kind] = (sum(v) / len(v), k)
