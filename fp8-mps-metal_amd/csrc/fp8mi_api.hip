@@ -254,7 +254,7 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
 #ifdef FP8MI_DIAG  // diagnostic library only: schedule variants of the ring kernel (7..13, 30..37), the producer / consumer kernel
                    // (15..24) and its timing-only ablations (201..207)
         if (K > 0 && fp8mi_gemm_supported(p)) {
-            if ((kernel >= 7 && kernel <= 13) || (kernel >= 30 && kernel <= 37)) return hip_result(fp8mi_launch_gemm(p, kernel, s), "gemm-variant");
+            if ((kernel >= 7 && kernel <= 13) || (kernel >= 30 && kernel <= 39) || (kernel >= 120 && kernel <= 129)) return hip_result(fp8mi_launch_gemm(p, kernel, s), "gemm-variant");
             if ((kernel >= 15 && kernel <= 29) || (kernel >= 200 && kernel < 220)) return hip_result(fp8mi_launch_gemm_pc(p, kernel, s), "gemm-pc");
         }
 #endif

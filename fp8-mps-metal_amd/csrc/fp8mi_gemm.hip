@@ -59,7 +59,7 @@ namespace {
 template <int BM, int BN, int WM, int WN, int NSTAGE_, int MODE_ = 0, int ABL_ = 0, int KS_ = 1, int LD_ = 0>
 struct Cfg {
     static constexpr int KS = KS_;      // K-steps (of 128 bytes) per ring stage: KS = 2 halves the barriers per byte
-    static constexpr int ABL = ABL_;    // unused (the ablation study moved to the producer/consumer kernel's diagnostic build)
+    static constexpr int PFD = ABL_;    // L2 prefetch distance in ring stages beyond the stage being staged (0 = none): see prefetch_stage
     static constexpr int MODE = MODE_;  // 0: stage DMA issued first, then fragment reads + MFMAs; 1: fragment reads first (see run_tile)
     static constexpr int NSTAGE = NSTAGE_;
     static constexpr int PF = NSTAGE_ - 1;  // K-steps of loads in flight
@@ -155,6 +155,8 @@ struct StagePlan {
     uint32_t sa, sb;    // uniform byte stride between the wave's consecutive A / B groups
     int rows_a, rows_b; // valid rows of this tile
     bool full;          // interior tile: no row masking
+    uint32_t pf_off;    // C::PFD: this lane's line of the B panel's share to prefetch (kOOB: none)
+    u32x4 pf_rsrc;      // ... and the B panel's descriptor as plain words (an asm operand)
 };
 
 template <typename C, bool TAIL>
@@ -224,6 +226,16 @@ FP8MI_DEVICE void issue_any(const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra, _
     else issue_stage<C, false>(pl, ra, rb, stage, wave, step * (BK * C::KS), K);
 }
 
+// L2 prefetch (C::PFD > 0).  The tiles an XCD runs at one time are 4 m-tiles x 8 n-tiles (tile_of_block): a B panel - the
+// weights, streamed from HBM - has 4 readers that ask for the same lines at the same time, and every one of them waits out
+// the HBM latency inside the ring's prefetch window.  Wave 0 of each tile touches one dword per 128-byte line of ITS quarter of
+// the panel for a stage PFD stages beyond the one being staged; the others then hit the L2.  The load's result is never used;
+// the register it lands in (`sink`) is carried through the loop so that hipcc does not hand it to anything else.
+FP8MI_DEVICE void prefetch_stage(uint32_t &sink, uint32_t voff, u32x4 rsrc, uint32_t koff)
+{
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(sink) : "v"(voff), "s"(rsrc), "s"(koff) : "memory");
+}
+
 template <typename C, bool SCRUB>
 FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra,
                            __amdgpu_buffer_rsrc_t rb, int wave, int wm0, int wn0, uint32_t off1, uint32_t off2,
@@ -249,11 +261,17 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
     // rest already in the XCD's L2.  (Only the summation order changes.)
     int ks = rot;  // stage (relative to ks0) the next issue loads
     auto next_ks = [&]() { const int r = ks; ks = (ks + 1 == nk) ? 0 : ks + 1; return ks0 + r; };
+    uint32_t sink = 0;  // C::PFD: landing register of the L2 prefetch loads (never read)
+    auto prefetch = [&](int stage) {  // stage relative to ks0, clamped to this workgroup's last one
+        if (C::PFD > 0 && wave == 0) prefetch_stage(sink, pl.pf_off, pl.pf_rsrc, (uint32_t)((ks0 + min(stage, nk - 1)) * (BK * C::KS)));
+    };
 
     // prologue: PF stages in flight (stage s -> ring slot s)
 #pragma unroll
     for (int s = 0; s < C::PF; ++s)
         if (s < nk) issue_any<C>(pl, ra, rb, smem + s * C::kStageBytes, wave, next_ks(), nk_all, ktail, K);
+#pragma unroll
+    for (int s = 0; s < C::PFD; ++s) prefetch(C::PF + s);
 
     STAMP(p1_);
     int slot = 0;             // ring slot of step t
@@ -275,14 +293,20 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
             const uint8_t *st = smem + slot * C::kStageBytes;
             load_frags<C, SCRUB>(st, st + C::kGroupsA * 1024, wm0, wn0, off1, off2, xf, wf);
             __builtin_amdgcn_sched_barrier(0);
-            if (t + C::PF < nk) issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, next_ks(), nk_all, ktail, K);
+            if (t + C::PF < nk) {
+                issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, next_ks(), nk_all, ktail, K);
+                prefetch(t + C::PF + C::PFD);
+            }
             STAMP(s3);
             mfma_all<C>(xf, wf, acc);
 #pragma unroll
             for (int q = 1; q < C::KS; ++q)
                 compute_step<C, SCRUB>(st + q * C::kStepBytes, wm0, wn0, off1, off2, acc);
         } else {
-            if (t + C::PF < nk) issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, next_ks(), nk_all, ktail, K);
+            if (t + C::PF < nk) {
+                issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, next_ks(), nk_all, ktail, K);
+                prefetch(t + C::PF + C::PFD);
+            }
             STAMP(s3);
 #pragma unroll
             for (int q = 0; q < C::KS; ++q)
@@ -306,6 +330,7 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
     }
 #endif
     // all loads were waited for in the last iteration (newer_stages == 0); the caller's barrier makes the ring reusable
+    if (C::PFD > 0) asm volatile("" ::"v"(sink));  // the prefetch loads' landing register stays reserved up to here
 #ifdef FP8MI_STAMP
     STAMP(p2_);
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && wave == 0) {
@@ -435,6 +460,18 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThr
         pl.rows_a = (int)rows_a;
         pl.rows_b = (int)rows_b;
         pl.full = rows_a == BM && rows_b == BN;
+        pl.pf_off = kOOB;
+        if (C::PFD > 0) {
+            // this tile's quarter of its B panel's lines for one stage (B has 4 readers on the XCD: the m-tiles of its group)
+            constexpr int kLines = BN * C::KS / 4;
+            static_assert(C::PFD == 0 || kLines <= 64, "one prefetch instruction per stage");
+            const int li = (tile_m & 3) * kLines + lane, prow = li / C::KS, pk = li % C::KS;
+            if (lane < kLines && prow < (int)rows_b && (p.K % (BK * C::KS)) == 0) pl.pf_off = (uint32_t)(prow * p.ldb + pk * BK);
+            const uint64_t pb = (uint64_t)(p.B + n0 * p.ldb);
+            pl.pf_rsrc = u32x4{(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pb),
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(pb >> 32) & 0xFFFFu)),
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)min(bytes_b, (int64_t)0x7FFFFFFF)), 0x00020000u};
+        }
     }
 
     // ---- fragment read offsets (lane constant): row r = lane & 15, lane group g = lane >> 4
@@ -565,7 +602,7 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     // ahead of the stage DMA (C3 15.9 -> 15.3 us); the 256x256 tile runs its two wave groups half a K-step apart (FLUX 130 -> 124 us,
     // 8192^3 509 -> 479 us); for the 128x128 tile neither order is a consistent gain (shard +1.6 %, 8192^3 -4.5 %): it keeps the plain one.
     case FP8MI_KERNEL_GEMM_128: return launch<128, 128, 64, 32, 2, 0, 0, 1, 4>(p, s);   // 2 x 32 KiB ring: 2 workgroups / CU
-    case FP8MI_KERNEL_GEMM_128x64: return launch<128, 64, 32, 32, 3, 1, 0, 2, 4>(p, s);  // 3 x 48 KiB ring, 2 K-steps per stage
+    case FP8MI_KERNEL_GEMM_128x64: return launch<128, 64, 32, 32, 3, 1, 1, 2, 4>(p, s);  // 3 x 48 KiB ring, 2 K-steps per stage, L2 prefetch one stage beyond the ring (C3 16.0 -> 15.3 us)
     case FP8MI_KERNEL_GEMM_256: return launch<256, 256, 128, 64, 2, 2, 0, 1, 4>(p, s);   // 2 x 64 KiB ring, staggered wave groups
     case FP8MI_KERNEL_GEMM_64x128: return launch<64, 128, 32, 32, 3, 1, 0, 2, 4>(p, s);  // 3 x 48 KiB ring, for M <= 64
     case FP8MI_KERNEL_GEMM_256W: return fp8mi_launch_gemm256(p, 0, s);                   // (only chosen above when fp8mi_gemm256_supported)
@@ -578,6 +615,11 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     case 35: return launch<256, 256, 128, 64, 2, 2>(p, s);                     // 256x256, staggered, all waves load
     case 36: return launch<128, 128, 64, 32, 2, 2, 0, 1, 4>(p, s);             // 128x128, staggered, waves 0-3 load
     case 37: return launch<128, 128, 64, 32, 2, 2>(p, s);                      // 128x128, staggered, all waves load
+    case 38: return launch<128, 64, 32, 32, 3, 1, 0, 2, 4>(p, s);              // 128x64 without the L2 prefetch
+    case 39: return launch<128, 64, 32, 32, 3, 1, 2, 2, 4>(p, s);              //   ... two stages
+    case 120: return launch<128, 128, 64, 32, 2, 0, 1, 1, 4>(p, s);            // 128x128 + L2 prefetch one stage further
+    case 121: return launch<128, 128, 64, 32, 2, 0, 2, 1, 4>(p, s);            //   ... two stages
+    case 122: return launch<128, 128, 64, 32, 2, 0, 4, 1, 4>(p, s);            //   ... four stages
     case 7: return launch<128, 64, 64, 32, 6>(p, s);                           // 128x64, 4 waves
     case 8: return launch<128, 128, 64, 64, 4>(p, s);                          // 128x128, 4 waves, 4-stage ring
     case 9: return launch<256, 128, 64, 64, 3, 0, 0, 1, 4>(p, s);              // 256x128, 8 waves (0-3 load), 3 x 48 KiB

@@ -38,26 +38,30 @@ constexpr int kDumpRow = 8 * 1024;     // one fragment row
 // them to the LDS after the loop.
 constexpr int kTabBytes = 4 * 512 + 16;                  // per wave: four 128-entry tables, then scale_result
 constexpr int kTabBase = kRing256 + kFlagBytes;
+// the launch's uniform switches packed into one SGPR (ten separate fields kept alive across the tile loop ran hipcc out of SGPRs:
+// it parked booleans in VGPRs, spilled those to scratch and reloaded them - with a full vmcnt wait - in front of the K loop)
+enum { kFBias = 1, kFTransposed = 2, kFSaRow = 4, kFSbRow = 8, kFNanZero = 16, kFSr = 32, kFOutShift = 6, kFBiasTypeShift = 8 };
+
 struct TabRegs {       // as loaded: nothing here is USED before the K loop (a use would wait for the load in front of it)
     float sa[2], sb[2], sr;
     uint32_t bias[2];  // raw fp32 bits, or a zero-extended 16-bit pattern
 };
 
-FP8MI_DEVICE TabRegs load_tables(const MMParams &p, int64_t m_wave, int64_t n_wave, int lane)
+FP8MI_DEVICE TabRegs load_tables(const MMParams &p, int flags, int64_t m_wave, int64_t n_wave, int lane)
 {
     TabRegs t;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int i = lane + 64 * h;
-        t.sa[h] = p.scale_a[p.sa_row ? m_wave + i : 0];
-        t.sb[h] = p.scale_b[p.sb_row ? n_wave + i : 0];
+        t.sa[h] = p.scale_a[(flags & kFSaRow) ? m_wave + i : 0];
+        t.sb[h] = p.scale_b[(flags & kFSbRow) ? n_wave + i : 0];
         t.bias[h] = 0u;
     }
     t.sr = 1.0f;
-    if (p.scale_result) t.sr = p.scale_result[0];
-    if (p.bias != nullptr) {
-        const int64_t base = p.transposed ? m_wave : n_wave;
-        if (p.bias_dtype == FP8MI_F32) {
+    if (flags & kFSr) t.sr = p.scale_result[0];
+    if (flags & kFBias) {
+        const int64_t base = (flags & kFTransposed) ? m_wave : n_wave;
+        if (((flags >> kFBiasTypeShift) & 3) == FP8MI_F32) {
             t.bias[0] = ((const uint32_t *)p.bias)[base + lane];
             t.bias[1] = ((const uint32_t *)p.bias)[base + lane + 64];
         } else {
@@ -68,20 +72,21 @@ FP8MI_DEVICE TabRegs load_tables(const MMParams &p, int64_t m_wave, int64_t n_wa
     return t;
 }
 
-FP8MI_DEVICE void store_tables(const MMParams &p, const TabRegs &t, float *tab, int lane)
+FP8MI_DEVICE void store_tables(int flags, const TabRegs &t, float *tab, int lane)
 {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         float b = 0.0f;
-        if (p.bias != nullptr) {
-            if (p.bias_dtype == FP8MI_F32) b = __builtin_bit_cast(float, t.bias[h]);
-            else if (p.bias_dtype == FP8MI_BF16) b = __builtin_bit_cast(float, t.bias[h] << 16);
+        const int bt = (flags >> kFBiasTypeShift) & 3;
+        if (flags & kFBias) {
+            if (bt == FP8MI_F32) b = __builtin_bit_cast(float, t.bias[h]);
+            else if (bt == FP8MI_BF16) b = __builtin_bit_cast(float, t.bias[h] << 16);
             else b = (float)__builtin_bit_cast(_Float16, (uint16_t)t.bias[h]);
         }
         tab[lane + 64 * h] = t.sa[h];
         tab[128 + lane + 64 * h] = t.sb[h];
-        tab[256 + lane + 64 * h] = p.transposed ? 0.0f : b;
-        tab[384 + lane + 64 * h] = p.transposed ? b : 0.0f;
+        tab[256 + lane + 64 * h] = (flags & kFTransposed) ? 0.0f : b;
+        tab[384 + lane + 64 * h] = (flags & kFTransposed) ? b : 0.0f;
     }
     tab[512] = t.sr;
 }
@@ -99,12 +104,17 @@ typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
 typedef __attribute__((address_space(1))) uint8_t glb_u8;
 
 template <int OUT, bool BIAS, bool TRANSPOSED, bool TABLES>
-FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave, int64_t n_wave, int lane)
+FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave, int64_t n_wave, int64_t ldc, int lane)
 {
     constexpr int kEsz = OUT == FP8MI_F32 ? 4 : 2;
     constexpr int kBatch = 4;
     const int pp = lane & 15, rsub = lane >> 4;
-    glb_u8 *gC = (glb_u8 *)p.C + (m_wave * p.ldc + n_wave) * kEsz;
+    // the wave tile of C as a raw buffer: 32-bit offsets in the store instead of 64-bit pointer arithmetic per row
+    __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)((uint8_t *)p.C + (m_wave * ldc + n_wave) * kEsz), 0,
+                                                                  0x7FFFFFFF, 0x00020000);
+    constexpr int kNt = 2;                         // aux: streaming (nt) store - C is written once and not re-read here
+    const uint32_t ldc_b = (uint32_t)(ldc * kEsz);
+    const bool has_sr = (flags & kFSr) != 0;        // uniform: the multiplication is skipped as a block when there is none
     const float sa_u = tab[0], sb_u = tab[128];   // per-tensor: every entry of the table is the scale
     f32x4 nan_sum = {0.0f, 0.0f, 0.0f, 0.0f};
     // two batches per trip where registers allow: the LDS reads of the second are scheduled above the arithmetic of the first
@@ -132,13 +142,11 @@ FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, float sr, lds_cu8 *dump, lds
             }
             if (BIAS && TRANSPOSED) bm[b] = tab[384 + row];
         }
+        float v[kBatch][8];
 #pragma unroll
         for (int b = 0; b < kBatch; ++b) {
-            const int rr = (it0 + b) * 4 + rsub, r = rr & 15;
-            const int col = (pp ^ (r >> 1)) * 8, row = half * 64 + rr;
             nan_sum += q0[b] + q1[b];
             const f32x4 lo = q0[b], hi = q1[b];
-            float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float a = j < 4 ? lo[j & 3] : hi[j & 3];
@@ -146,18 +154,29 @@ FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, float sr, lds_cu8 *dump, lds
                 const float s_b = TABLES ? (j < 4 ? sb0[b][j & 3] : sb1[b][j & 3]) : sb_u;
                 float x = TRANSPOSED ? (a * s_b) * s_a : (a * s_a) * s_b;
                 if (BIAS) x = x + (TRANSPOSED ? bm[b] : (j < 4 ? bn0[b][j & 3] : bn1[b][j & 3]));
-                v[j] = x * sr;                                  // (sr = 1.0f when there is no scale_result: exact)
+                v[b][j] = x;
             }
-            glb_u8 *dst = gC + ((int64_t)row * p.ldc + col) * kEsz;
+        }
+        if (has_sr) {
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[b][j] = v[b][j] * sr;
+        }
+#pragma unroll
+        for (int b = 0; b < kBatch; ++b) {
+            const int rr = (it0 + b) * 4 + rsub, r = rr & 15;
+            const int col = (pp ^ (r >> 1)) * 8, row = half * 64 + rr;
+            const int off = (int)((uint32_t)row * ldc_b + (uint32_t)(col * kEsz));
             if (OUT == FP8MI_F32) {
-                __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, (__attribute__((address_space(1))) f32x4 *)dst);
-                __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, (__attribute__((address_space(1))) f32x4 *)(dst + 16));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[b][0], v[b][1], v[b][2], v[b][3]}), rc, off, 0, kNt);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[b][4], v[b][5], v[b][6], v[b][7]}), rc, off + 16, 0, kNt);
             } else {
                 uint32_t w[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {   // one packed convert (round to nearest even) per output pair
                     typedef float f32x2_t __attribute__((ext_vector_type(2)));
-                    const f32x2_t pr = {v[2 * j], v[2 * j + 1]};
+                    const f32x2_t pr = {v[b][2 * j], v[b][2 * j + 1]};
                     if (OUT == FP8MI_BF16) {
                         typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
                         w[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, bf16x2_t));
@@ -166,7 +185,7 @@ FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, float sr, lds_cu8 *dump, lds
                         w[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, f16x2_t));
                     }
                 }
-                __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, (__attribute__((address_space(1))) u32x4 *)dst);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{w[0], w[1], w[2], w[3]}, rc, off, 0, kNt);
             }
         }
     }
@@ -174,29 +193,30 @@ FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, float sr, lds_cu8 *dump, lds
 }
 
 template <int OUT, bool TABLES>
-FP8MI_DEVICE f32x4 epilogue_half_flags(const MMParams &p, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave,
-                                       int64_t n_wave, int lane)
+FP8MI_DEVICE f32x4 epilogue_half_flags(const MMParams &p, int flags, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave,
+                                       int64_t n_wave, int64_t ldc, int lane)
 {
-    if (p.bias == nullptr) {
-        if (p.transposed) return epilogue_half<OUT, false, true, TABLES>(p, sr, dump, tab, half, m_wave, n_wave, lane);
-        return epilogue_half<OUT, false, false, TABLES>(p, sr, dump, tab, half, m_wave, n_wave, lane);
+    if (!(flags & kFBias)) {
+        if (flags & kFTransposed) return epilogue_half<OUT, false, true, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane);
+        return epilogue_half<OUT, false, false, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane);
     }
-    if (p.transposed) return epilogue_half<OUT, true, true, TABLES>(p, sr, dump, tab, half, m_wave, n_wave, lane);
-    return epilogue_half<OUT, true, false, TABLES>(p, sr, dump, tab, half, m_wave, n_wave, lane);
+    if (flags & kFTransposed) return epilogue_half<OUT, true, true, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane);
+    return epilogue_half<OUT, true, false, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane);
 }
 
-FP8MI_DEVICE f32x4 epilogue_half_any(const MMParams &p, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave,
-                                     int64_t n_wave, int lane)
+FP8MI_DEVICE f32x4 epilogue_half_any(const MMParams &p, int flags, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave,
+                                     int64_t n_wave, int64_t ldc, int lane)
 {
-    const bool tables = p.sa_row || p.sb_row;
-    if (p.out_dtype == FP8MI_F32)
-        return tables ? epilogue_half_flags<FP8MI_F32, true>(p, sr, dump, tab, half, m_wave, n_wave, lane)
-                      : epilogue_half_flags<FP8MI_F32, false>(p, sr, dump, tab, half, m_wave, n_wave, lane);
-    if (p.out_dtype == FP8MI_BF16)
-        return tables ? epilogue_half_flags<FP8MI_BF16, true>(p, sr, dump, tab, half, m_wave, n_wave, lane)
-                      : epilogue_half_flags<FP8MI_BF16, false>(p, sr, dump, tab, half, m_wave, n_wave, lane);
-    return tables ? epilogue_half_flags<FP8MI_F16, true>(p, sr, dump, tab, half, m_wave, n_wave, lane)
-                  : epilogue_half_flags<FP8MI_F16, false>(p, sr, dump, tab, half, m_wave, n_wave, lane);
+    const bool tables = (flags & (kFSaRow | kFSbRow)) != 0;
+    const int od = (flags >> kFOutShift) & 3;
+    if (od == FP8MI_F32)
+        return tables ? epilogue_half_flags<FP8MI_F32, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane)
+                      : epilogue_half_flags<FP8MI_F32, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane);
+    if (od == FP8MI_BF16)
+        return tables ? epilogue_half_flags<FP8MI_BF16, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane)
+                      : epilogue_half_flags<FP8MI_BF16, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane);
+    return tables ? epilogue_half_flags<FP8MI_F16, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane)
+                  : epilogue_half_flags<FP8MI_F16, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane);
 }
 
 #ifdef FP8MI_STAMP  // diagnostic build only: phase stamps of wave 0 of every workgroup (tools/stamp_gemm256.py)
@@ -220,15 +240,21 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
     STAMP256(0);
     const MMParams p = pin_params(p_in);
     FP8MI_PIN_S(tiles_m); FP8MI_PIN_S(tiles_n); FP8MI_PIN_S(nwg);
+    int flags = (p.bias ? kFBias : 0) | (p.transposed ? kFTransposed : 0) | (p.sa_row ? kFSaRow : 0) | (p.sb_row ? kFSbRow : 0) |
+                (p.nan_zero ? kFNanZero : 0) | (p.scale_result ? kFSr : 0) | (p.out_dtype << kFOutShift) | (p.bias_dtype << kFBiasTypeShift);
+    FP8MI_PIN_S(flags);
     __shared__ __attribute__((aligned(16))) uint8_t smem[kRing256 + kFlagBytes + 4 * kTabBytes];
     if (threadIdx.x == 0) *(__attribute__((address_space(3))) volatile int *)(lds_void *)(smem + kRing256) = 0;  // NaN verdict word (ordered by the K loop's barriers)
 
     int tile_m, tile_n, kslice, wg;
     tile_of_block(blockIdx.x, nwg, tiles_m, tiles_n, tile_m, tile_n, kslice, wg);
     const int64_t m0 = (int64_t)tile_m * kBM, n0 = (int64_t)tile_n * kBN;
-    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    FP8MI_PIN_S(wave);   // (opaque: else hipcc keeps threadIdx.x alive - in scratch - to re-derive it inside the pass loop)
-    const int wm0 = (wave & 1) * 128, wn0 = (wave >> 1) * 128;
+    // Which quadrant of the tile a wave owns and which row groups it stages only has to be a bijection onto 0..3: the id of the
+    // SIMD the wave runs on serves - a wave of this kernel owns its SIMD's whole register file (512 entries: the asm's clobber
+    // list sees to that), so the four waves of a workgroup sit on four different SIMDs.  Read from HW_ID (bits 5:4) where it is
+    // needed instead of being derived from threadIdx.x once: held in an SGPR across the tile loop it was spilled - through a
+    // VGPR to scratch - and reloaded with a full vmcnt wait in front of the K loop.
+#define FP8MI_SIMD_ID() ((int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4))
 
     // raw buffer descriptors (stride 0, range-checked) rebased to this tile's first row; whole tiles only
     const uint64_t pa = (uint64_t)(p.A + m0 * p.lda), pb = (uint64_t)(p.B + n0 * p.ldb);
@@ -257,8 +283,11 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
         //  invariants, hipcc hoists the ~20 registers of asm operands and epilogue addresses out of the loop and keeps
         //  them in scratch across the epilogue)
         int lane_l;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_l));
-        const TabRegs tabs = load_tables(p, m0 + wm0, n0 + wn0, lane_l);   // in flight under the K loop, stored to the LDS behind it
+        int fl_l = flags;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_l), "+s"(fl_l));
+        const int wave = FP8MI_SIMD_ID();
+        const int wm0 = (wave & 1) * 128, wn0 = (wave >> 1) * 128;
+        const TabRegs tabs = load_tables(p, fl_l, m0 + wm0, n0 + wn0, lane_l);   // in flight under the K loop, stored to the LDS behind it
         // staging plan (fp8mi_gemm.hip): wave w stages the 1-KiB groups w, w + 4, ... of both operands; lane -> (row, swizzled chunk)
         const int row0 = wave * 8 + (lane_l >> 3);
         const int chunk = (lane_l & 7) ^ (((wave & 1) * 4 + (lane_l >> 4)) & 7);
@@ -299,18 +328,21 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
         (void)t0; (void)t1;
         if (pass == 0) STAMP256(2);
         int lane_e;
-        int64_t m_wave = m0 + wm0, n_wave = n0 + wn0;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e), "+s"(m_wave), "+s"(n_wave));
-        lds_cu8 *dump = (lds_cu8 *)(lds_void *)(smem + wave * kDumpWave);
-        float *tabw = (float *)(smem + kTabBase + wave * kTabBytes);
-        store_tables(p, tabs, tabw, lane_e);
+        const int wave_e = FP8MI_SIMD_ID();   // (read again: nothing of the wave's identity is kept across the K loop)
+        int64_t m_wave = m0 + (wave_e & 1) * 128, n_wave = n0 + (wave_e >> 1) * 128;
+        int fl = flags;        // (the switches and ldc too: their tests and multiples are then formed here, not in SGPRs held across the loop)
+        int64_t ldc_e = p.ldc;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e), "+s"(m_wave), "+s"(n_wave), "+s"(fl), "+s"(ldc_e));
+        lds_cu8 *dump = (lds_cu8 *)(lds_void *)(smem + wave_e * kDumpWave);
+        float *tabw = (float *)(smem + kTabBase + wave_e * kTabBytes);
+        store_tables(fl, tabs, tabw, lane_e);
         lds_cf32 *tab = (lds_cf32 *)(lds_void *)tabw;
         const float sr = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tabw[512])));
-        f32x4 t = epilogue_half_any(p, sr, dump, tab, 0, m_wave, n_wave, lane_e);
+        f32x4 t = epilogue_half_any(p, fl, sr, dump, tab, 0, m_wave, n_wave, ldc_e, lane_e);
         if (pass == 0) STAMP256(3);
         FP8MI_GEMM256_DUMP_HI();
-        t += epilogue_half_any(p, sr, dump, tab, 1, m_wave, n_wave, lane_e);
-        if (!p.nan_zero || pass == 1) break;
+        t += epilogue_half_any(p, fl, sr, dump, tab, 1, m_wave, n_wave, ldc_e, lane_e);
+        if (!(flags & kFNanZero) || pass == 1) break;
         const float sum = (t[0] + t[1]) + (t[2] + t[3]);
         if (sum != sum) *flag = 1;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -332,7 +364,8 @@ bool fp8mi_gemm256_supported(const MMParams &p)
 {
     const int esz = p.out_dtype == FP8MI_F32 ? 4 : 2;
     return fp8mi_gemm_supported(p) && (p.M % kBM) == 0 && (p.N % kBN) == 0 && (p.K % BK) == 0 && p.K >= 2 * BK && p.split <= 1 &&
-           ((p.ldc * esz) % 16) == 0 && (((uintptr_t)p.C) % 16) == 0 && (p.M / kBM) * (p.N / kBN) <= 0x7FFFFFFF;
+           ((p.ldc * esz) % 16) == 0 && (((uintptr_t)p.C) % 16) == 0 && (p.M / kBM) * (p.N / kBN) <= 0x7FFFFFFF &&
+           p.ldc * esz * 128 < 0x7FFF0000;   // the epilogue addresses a wave tile (128 rows) with 32-bit offsets
 }
 
 #ifdef FP8MI_STAMP

@@ -20,7 +20,7 @@ a = np.array(list(buf), dtype=np.float64).reshape(1024, 8)
 a = a[a[:, 7] > 0]
 print(f"{name}: {len(a)} workgroups stamped")
 t_first = a[:, 6].min()
-names = ("entry -> K loop (setup)", "K loop (asm: prologue DMA .. last MFMA)", "NaN vote + barrier", "epilogue issue", "store drain (vmcnt 0)")
+names = ("entry -> K loop (setup)", "K loop (asm: prologue DMA .. dump of rows 0-3)", "epilogue, fragment rows 0-3 (from the dump)", "dump + epilogue, fragment rows 4-7", "store drain (vmcnt 0)")
 wall = (a[:, 7] - a[:, 6]) / 100.0   # us (100 MHz)
 clk = (a[:, 5] - a[:, 0]) / np.maximum(a[:, 7] - a[:, 6], 1) * 0.1
 print(f"shader clock {clk.mean():.2f} GHz; workgroup wall {wall.mean():.1f} us (min {wall.min():.1f}, max {wall.max():.1f})")
