@@ -297,17 +297,27 @@ def time_steps(w, steps, warmup, use_graph, world, n_streams=1):
 
 
 def kernel_durations(w, launches):
-    """Average pure device duration (s) of the workload's kernel, per-dispatch events."""
+    """Average pure device duration (s) of the workload's kernel, per-dispatch events.  The launches are issued eagerly
+    from Python; after an idle gap (or while the host is still busy with the CPU baseline's threads) the device clocks
+    down between them and a 6 us kernel reads 9 us.  So: an untimed burst first, then two timed passes, and the pass
+    with the lower AVERAGE is reported (every figure is the mean over all dispatches of one pass)."""
     s = torch.cuda.current_stream(w.dev).cuda_stream
-    torch.cuda.synchronize(w.dev)
-    with L.kernel_timer(launches) as kt:
-        for i in range(launches):
+    best = None
+    for _ in range(2):
+        for i in range(min(launches, 64)):
             w.launch(i, s)
-    torch.cuda.synchronize(w.dev)
-    ms = sorted(kt.ms)
-    if not ms:
-        return None
-    return {"avg_s": sum(ms) / len(ms) * 1e-3, "min_s": ms[0] * 1e-3, "median_s": ms[len(ms) // 2] * 1e-3, "n": len(ms)}
+        torch.cuda.synchronize(w.dev)
+        with L.kernel_timer(launches) as kt:
+            for i in range(launches):
+                w.launch(i, s)
+        torch.cuda.synchronize(w.dev)
+        ms = sorted(kt.ms)
+        if not ms:
+            return None
+        r = {"avg_s": sum(ms) / len(ms) * 1e-3, "min_s": ms[0] * 1e-3, "median_s": ms[len(ms) // 2] * 1e-3, "n": len(ms)}
+        if best is None or r["avg_s"] < best["avg_s"]:
+            best = r
+    return best
 
 
 _PROBE = None
