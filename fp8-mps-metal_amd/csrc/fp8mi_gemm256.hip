@@ -1,7 +1,7 @@
 // 256x256-tile FP8 e4m3fn GEMM with ONE wave per SIMD and a hand-scheduled K loop (gfx950).
 //
 // Same contract and the same bits as the ring kernels of fp8mi_gemm.hip (same LDS image, same fragment -> MFMA operand
-// map, K-steps added in order), for the shapes that are made of whole 256x256 tiles and whole 128-byte K-steps:
+// map, K-steps added in order), for shapes of whole 256-column tiles and whole 128-byte K-steps (any M):
 //
 //     C[m,n] = cast(((sum_k dec(A[m,k]) dec(B[n,k])) * sa[m] * sb[n] + bias[n]) * sr)        (fp8_matmul.metal:99-147)
 //
@@ -50,23 +50,28 @@ struct TabRegs {       // as loaded: nothing here is USED before the K loop (a u
 FP8MI_DEVICE TabRegs load_tables(const MMParams &p, int flags, int64_t m_wave, int64_t n_wave, int lane)
 {
     TabRegs t;
+    // rows of a ragged last m-tile beyond M take the entry of row M - 1 (any valid address: they are never stored); the clamp is
+    // formed from scalars and one 32-bit min per lane (as 64-bit vector arithmetic its constants were hoisted and spilled)
+    const int m_last = (int)p.M - 1, m_base = min((int)m_wave, m_last);   // (32-bit: M < 2^31, fp8mi_gemm256_supported)
+    const int m_lim = max(min(m_last - m_base, 127), 0);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int i = lane + 64 * h;
-        t.sa[h] = p.scale_a[(flags & kFSaRow) ? m_wave + i : 0];
+        t.sa[h] = p.scale_a[(flags & kFSaRow) ? m_base + min(i, m_lim) : 0];
         t.sb[h] = p.scale_b[(flags & kFSbRow) ? n_wave + i : 0];
         t.bias[h] = 0u;
     }
     t.sr = 1.0f;
     if (flags & kFSr) t.sr = p.scale_result[0];
     if (flags & kFBias) {
-        const int64_t base = (flags & kFTransposed) ? m_wave : n_wave;
+        const int64_t i0 = (flags & kFTransposed) ? m_base + min(lane, m_lim) : n_wave + lane;
+        const int64_t i1 = (flags & kFTransposed) ? m_base + min(lane + 64, m_lim) : n_wave + lane + 64;
         if (((flags >> kFBiasTypeShift) & 3) == FP8MI_F32) {
-            t.bias[0] = ((const uint32_t *)p.bias)[base + lane];
-            t.bias[1] = ((const uint32_t *)p.bias)[base + lane + 64];
+            t.bias[0] = ((const uint32_t *)p.bias)[i0];
+            t.bias[1] = ((const uint32_t *)p.bias)[i1];
         } else {
-            t.bias[0] = ((const uint16_t *)p.bias)[base + lane];
-            t.bias[1] = ((const uint16_t *)p.bias)[base + lane + 64];
+            t.bias[0] = ((const uint16_t *)p.bias)[i0];
+            t.bias[1] = ((const uint16_t *)p.bias)[i1];
         }
     }
     return t;
@@ -104,14 +109,15 @@ typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
 typedef __attribute__((address_space(1))) uint8_t glb_u8;
 
 template <int OUT, bool BIAS, bool TRANSPOSED, bool TABLES>
-FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave, int64_t n_wave, int64_t ldc, int lane)
+FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave, int64_t n_wave, int64_t ldc, int rows_ok, int lane)
 {
     constexpr int kEsz = OUT == FP8MI_F32 ? 4 : 2;
     constexpr int kBatch = 4;
     const int pp = lane & 15, rsub = lane >> 4;
     // the wave tile of C as a raw buffer: 32-bit offsets in the store instead of 64-bit pointer arithmetic per row
+    // (num_records = the wave tile's valid rows: stores to rows of a ragged last m-tile beyond M are out of range and dropped)
     __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)((uint8_t *)p.C + (m_wave * ldc + n_wave) * kEsz), 0,
-                                                                  0x7FFFFFFF, 0x00020000);
+                                                                  (int)((int64_t)rows_ok * ldc * kEsz), 0x00020000);
     constexpr int kNt = 2;                         // aux: streaming (nt) store - C is written once and not re-read here
     const uint32_t ldc_b = (uint32_t)(ldc * kEsz);
     const bool has_sr = (flags & kFSr) != 0;        // uniform: the multiplication is skipped as a block when there is none
@@ -194,29 +200,29 @@ FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8
 
 template <int OUT, bool TABLES>
 FP8MI_DEVICE f32x4 epilogue_half_flags(const MMParams &p, int flags, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave,
-                                       int64_t n_wave, int64_t ldc, int lane)
+                                       int64_t n_wave, int64_t ldc, int rows_ok, int lane)
 {
     if (!(flags & kFBias)) {
-        if (flags & kFTransposed) return epilogue_half<OUT, false, true, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane);
-        return epilogue_half<OUT, false, false, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane);
+        if (flags & kFTransposed) return epilogue_half<OUT, false, true, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane);
+        return epilogue_half<OUT, false, false, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane);
     }
-    if (flags & kFTransposed) return epilogue_half<OUT, true, true, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane);
-    return epilogue_half<OUT, true, false, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane);
+    if (flags & kFTransposed) return epilogue_half<OUT, true, true, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane);
+    return epilogue_half<OUT, true, false, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane);
 }
 
 FP8MI_DEVICE f32x4 epilogue_half_any(const MMParams &p, int flags, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave,
-                                     int64_t n_wave, int64_t ldc, int lane)
+                                     int64_t n_wave, int64_t ldc, int rows_ok, int lane)
 {
     const bool tables = (flags & (kFSaRow | kFSbRow)) != 0;
     const int od = (flags >> kFOutShift) & 3;
     if (od == FP8MI_F32)
-        return tables ? epilogue_half_flags<FP8MI_F32, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane)
-                      : epilogue_half_flags<FP8MI_F32, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane);
+        return tables ? epilogue_half_flags<FP8MI_F32, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane)
+                      : epilogue_half_flags<FP8MI_F32, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane);
     if (od == FP8MI_BF16)
-        return tables ? epilogue_half_flags<FP8MI_BF16, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane)
-                      : epilogue_half_flags<FP8MI_BF16, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane);
-    return tables ? epilogue_half_flags<FP8MI_F16, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane)
-                  : epilogue_half_flags<FP8MI_F16, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, lane);
+        return tables ? epilogue_half_flags<FP8MI_BF16, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane)
+                      : epilogue_half_flags<FP8MI_BF16, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane);
+    return tables ? epilogue_half_flags<FP8MI_F16, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane)
+                  : epilogue_half_flags<FP8MI_F16, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane);
 }
 
 #ifdef FP8MI_STAMP  // diagnostic build only: phase stamps of wave 0 of every workgroup (tools/stamp_gemm256.py)
@@ -256,9 +262,10 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
     // VGPR to scratch - and reloaded with a full vmcnt wait in front of the K loop.
 #define FP8MI_SIMD_ID() ((int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4))
 
-    // raw buffer descriptors (stride 0, range-checked) rebased to this tile's first row; whole tiles only
+    // raw buffer descriptors (stride 0, range-checked) rebased to this tile's first row
     const uint64_t pa = (uint64_t)(p.A + m0 * p.lda), pb = (uint64_t)(p.B + n0 * p.ldb);
-    const int64_t bytes_a = (int64_t)(kBM - 1) * p.lda + p.K, bytes_b = (int64_t)(kBN - 1) * p.ldb + p.K;
+    const int64_t rows_a = min(kBM, (int)p.M - (int)m0);   // the last m-tile may be ragged: rows beyond M read as zeros (range check) and are not stored
+    const int64_t bytes_a = (rows_a - 1) * p.lda + p.K, bytes_b = (int64_t)(kBN - 1) * p.ldb + p.K;
     u32x4 ra = {(uint32_t)pa, (uint32_t)(pa >> 32) & 0xFFFFu, (uint32_t)min(bytes_a, (int64_t)0x7FFFFFFF), 0x00020000u};
     u32x4 rb = {(uint32_t)pb, (uint32_t)(pb >> 32) & 0xFFFFu, (uint32_t)min(bytes_b, (int64_t)0x7FFFFFFF), 0x00020000u};
     ra[0] = __builtin_amdgcn_readfirstlane(ra[0]); ra[1] = __builtin_amdgcn_readfirstlane(ra[1]);
@@ -304,9 +311,18 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
         // (tile_of_block), so an A panel has 8 readers and a B panel 4; each warms its share of the lines of a later stage:
         // wave 0 rows 64 (tile_m & 3) .. + 63 of its B panel, wave 1 rows 32 (tile_n & 7) .. + 31 of its A panel (other lanes
         // point outside the buffer: no access).  Speed only: whoever else reads the panel finds the lines in the L2.
-        const uint32_t pfoff = wave == 0 ? (uint32_t)((64 * (tile_m & 3) + lane_l) * p.ldb)
-                               : (wave == 1 && lane_l < 32) ? (uint32_t)((32 * (tile_n & 7) + lane_l) * p.lda) : kOOB;
-        const u32x4 rpf = wave == 0 ? rb : ra;
+        // (diagnostic variants 19-21: every wave takes a quarter of both shares - lanes 0-15 B lines, 16-23 A lines - so that the
+        //  96 lines that may miss to HBM enter the L1's miss queue in four smaller groups)
+        constexpr bool kSplitPf = V >= 19 && V <= 21;
+        uint32_t pfoff;
+        if (!kSplitPf) {
+            pfoff = wave == 0 ? (uint32_t)((64 * (tile_m & 3) + lane_l) * p.ldb)
+                              : (wave == 1 && lane_l < 32 && 32 * (tile_n & 7) + lane_l < (int)rows_a) ? (uint32_t)((32 * (tile_n & 7) + lane_l) * p.lda) : kOOB;
+        } else {
+            pfoff = lane_l < 16 ? (uint32_t)((64 * (tile_m & 3) + 16 * wave + lane_l) * p.ldb) : kOOB;
+        }
+        const uint32_t wave_s = (uint32_t)wave;
+        const u32x4 rpf = (kSplitPf || wave == 0) ? rb : ra;   // (the split variants prefetch B lines only: the A panel is re-read 48x and stays in the L2)
         const uint32_t klast = (uint32_t)((nk - 1) * BK);
         // accumulator dump (gen_gemm256_loop.py): row fr of each fragment row, 16-byte chunk (4 tn + fg) ^ fr
         const uint32_t drow = lds0 + wave * kDumpWave + fr * 512, dkey = (uint32_t)((fg ^ fr) << 4);
@@ -333,15 +349,16 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
         int fl = flags;        // (the switches and ldc too: their tests and multiples are then formed here, not in SGPRs held across the loop)
         int64_t ldc_e = p.ldc;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e), "+s"(m_wave), "+s"(n_wave), "+s"(fl), "+s"(ldc_e));
+        const int rows_ok = min(max((int)p.M - (int)m_wave, 0), 128);   // valid rows of this wave's tile (ragged last m-tile)
         lds_cu8 *dump = (lds_cu8 *)(lds_void *)(smem + wave_e * kDumpWave);
         float *tabw = (float *)(smem + kTabBase + wave_e * kTabBytes);
         store_tables(fl, tabs, tabw, lane_e);
         lds_cf32 *tab = (lds_cf32 *)(lds_void *)tabw;
         const float sr = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tabw[512])));
-        f32x4 t = epilogue_half_any(p, fl, sr, dump, tab, 0, m_wave, n_wave, ldc_e, lane_e);
+        f32x4 t = epilogue_half_any(p, fl, sr, dump, tab, 0, m_wave, n_wave, ldc_e, rows_ok, lane_e);
         if (pass == 0) STAMP256(3);
         FP8MI_GEMM256_DUMP_HI();
-        t += epilogue_half_any(p, fl, sr, dump, tab, 1, m_wave, n_wave, ldc_e, lane_e);
+        t += epilogue_half_any(p, fl, sr, dump, tab, 1, m_wave, n_wave, ldc_e, rows_ok, lane_e);
         if (!(flags & kFNanZero) || pass == 1) break;
         const float sum = (t[0] + t[1]) + (t[2] + t[3]);
         if (sum != sum) *flag = 1;
@@ -359,12 +376,12 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
 
 }  // namespace
 
-// whole 256x256 tiles, whole K-steps (at least two), rows the vector epilogue can store, no split-K
+// whole 256-column tiles (any M: the last m-tile may be ragged), whole K-steps (at least two), rows the vector epilogue can store, no split-K
 bool fp8mi_gemm256_supported(const MMParams &p)
 {
     const int esz = p.out_dtype == FP8MI_F32 ? 4 : 2;
-    return fp8mi_gemm_supported(p) && (p.M % kBM) == 0 && (p.N % kBN) == 0 && (p.K % BK) == 0 && p.K >= 2 * BK && p.split <= 1 &&
-           ((p.ldc * esz) % 16) == 0 && (((uintptr_t)p.C) % 16) == 0 && (p.M / kBM) * (p.N / kBN) <= 0x7FFFFFFF &&
+    return fp8mi_gemm_supported(p) && p.M < 0x7FFFFF00 && (p.N % kBN) == 0 && (p.K % BK) == 0 && p.K >= 2 * BK && p.split <= 1 &&
+           ((p.ldc * esz) % 16) == 0 && (((uintptr_t)p.C) % 16) == 0 && ((p.M + kBM - 1) / kBM) * (p.N / kBN) <= 0x7FFFFFFF &&
            p.ldc * esz * 128 < 0x7FFF0000;   // the epilogue addresses a wave tile (128 rows) with 32-bit offsets
 }
 
@@ -377,7 +394,7 @@ extern "C" int fp8mi_debug_read_stamps256(unsigned long long *out, int n)
 
 int fp8mi_launch_gemm256(const MMParams &p, int variant, hipStream_t s)
 {
-    const int64_t tm = p.M / kBM, tn = p.N / kBN;
+    const int64_t tm = (p.M + kBM - 1) / kBM, tn = p.N / kBN;
     const unsigned grid = (unsigned)(tm * tn);
     switch (variant) {
     case 0: return fp8mi_launch(gemm256_kernel<0>, dim3(grid), dim3(kThreads256), s, p, (int)tm, (int)tn, (int)grid);

@@ -42,6 +42,7 @@ PRODUCT = dict(
     schedule=1,       # 1: DMA under MFMAs dma_first.. of the step, one barrier; 2: DMA as an even stream, two barriers (see step2)
     pf=2,             # > 0: each step one L2 prefetch instruction per wave for the stage `pf` steps ahead of the DMA's (see pf_group)
     pf_at=56,         # index of the MFMA after which it is issued (behind the step's last DMA)
+    pf_stagger=0,     # > 0: wave w issues it pf_stagger * (3 - w) MFMAs earlier (needs the kernel's per-wave split of the lines)
     # timing-only ablations (wrong results): which parts of the steady-state step are left out
     no_vmwait=False, no_dma=False, no_barrier=False, no_reads=False, no_mfma=False,
 )
@@ -64,6 +65,9 @@ VARIANTS = {
     16: dict(pf_at=20),
     17: dict(schedule=2),
     18: dict(schedule=2, xdelay=0),
+    19: dict(pf_at=56),              # + the kernel's per-wave split of the prefetch lines (kSplitPf)
+    20: dict(pf_stagger=12),         # ... issued at MFMA 20 / 32 / 44 / 56 by wave 0 / 1 / 2 / 3
+    21: dict(pf_stagger=4),
 }
 P = dict(PRODUCT)
 
@@ -93,21 +97,23 @@ def rdX(tm, which):
 
 
 def dma_block(slot_m0, kreg, first=True):
-    """16 DMA instructions of one stage as a list of 16 instruction groups."""
+    """16 DMA instructions of one stage as a list of 16 instruction groups.  The row part of the source offset travels in a
+    VGPR (v118 = va0 / vb0 + jo x row-group stride) and only k in the scalar offset: the hardware range-checks the VGPR offset
+    against the descriptor's num_records, so the rows of a ragged last m-tile beyond M read as zeros without a mask."""
     groups = []
     for j in range(16):
         g = []
         if j == 0:
-            g += [f"s_mov_b32 m0, {slot_m0}", f"s_mov_b32 %[t0], {kreg}"]
+            g += [f"s_mov_b32 m0, {slot_m0}", f"s_mov_b32 %[t0], {kreg}", "v_mov_b32 v118, %[va0]"]
         elif j == 8:
-            g += ["s_add_u32 m0, m0, 0x1000", f"s_mov_b32 %[t0], {kreg}"]
+            g += ["s_add_u32 m0, m0, 0x1000", "v_mov_b32 v118, %[vb0]"]
         else:
-            g += ["s_add_u32 m0, m0, 0x1000", f"s_add_u32 %[t0], %[t0], {'%[sa]' if j < 8 else '%[sb]'}"]
+            g += ["s_add_u32 m0, m0, 0x1000"]
         g += ["s_nop 0"]
         if j < 8:
-            g += ["buffer_load_dwordx4 %[va0], %[ra], %[t0] offen lds"]
+            g += ["buffer_load_dwordx4 v118, %[ra], %[t0] offen lds", "v_add_u32 v118, %[sa], v118"]
         else:
-            g += ["buffer_load_dwordx4 %[vb0], %[rb], %[t0] offen lds"]
+            g += ["buffer_load_dwordx4 v118, %[rb], %[t0] offen lds", "v_add_u32 v118, %[sb], v118"]
         groups.append(g)
     return groups
 
@@ -160,8 +166,12 @@ def step(dma, reads):
     if dma and not P["no_dma"]:
         for j, g in enumerate(dma_block("%[m0_c]", "%[k2]")):
             post[min(63, P["dma_first"] - 1 + j * P["dma_every"])] += g
-        if P["pf"]:
+        if P["pf"] and not P["pf_stagger"]:
             post[P["pf_at"]] += pf_group()
+        elif P["pf"]:
+            for w in range(4):   # one copy per wave, each behind a scalar test of the wave's index
+                g = [f"s_cmp_lg_u32 %[wave], {w}", f"s_cbranch_scc1 3{w}f"] + pf_group() + [f"3{w}:"]
+                post[P["pf_at"] - P["pf_stagger"] * (3 - w)] += g
     out = []
     for i in range(64):
         out += pre[i]
@@ -201,13 +211,16 @@ def dma_group2(j, slot_m0, kreg):
     """instruction j = 0..15 of a stage's stream: 0..7 B panel (LDS groups 32 + w + 4 jo), 8..15 A panel"""
     g = []
     if j == 0:
-        g += [f"s_add_u32 m0, {slot_m0}, 0x8000", f"s_mov_b32 %[t0], {kreg}"]
+        g += [f"s_add_u32 m0, {slot_m0}, 0x8000", f"s_mov_b32 %[t0], {kreg}", "v_mov_b32 v118, %[vb0]"]
     elif j == 8:
-        g += [f"s_sub_u32 m0, m0, {hex(0x8000 + 7 * 0x1000)}", "s_mul_i32 %[t1], %[sb], 7", "s_sub_u32 %[t0], %[t0], %[t1]"]
+        g += [f"s_sub_u32 m0, m0, {hex(0x8000 + 7 * 0x1000)}", "v_mov_b32 v118, %[va0]"]
     else:
-        g += ["s_add_u32 m0, m0, 0x1000", f"s_add_u32 %[t0], %[t0], {'%[sb]' if j < 8 else '%[sa]'}"]
+        g += ["s_add_u32 m0, m0, 0x1000"]
     g += ["s_nop 0"]
-    g += ["buffer_load_dwordx4 %[vb0], %[rb], %[t0] offen lds" if j < 8 else "buffer_load_dwordx4 %[va0], %[ra], %[t0] offen lds"]
+    if j < 8:
+        g += ["buffer_load_dwordx4 v118, %[rb], %[t0] offen lds", "v_add_u32 v118, %[sb], v118"]
+    else:
+        g += ["buffer_load_dwordx4 v118, %[ra], %[t0] offen lds", "v_add_u32 v118, %[sa], v118"]
     return g
 
 
@@ -352,8 +365,8 @@ def emit(name, lines, scrub):
     if scrub:
         outs += ['[vt0] "=&v"(vt0)', '[vt1] "=&v"(vt1)']
     ins = ['[va0] "v"(va0)', '[vb0] "v"(vb0)', '[vscale] "v"(vscale)', '[ra] "s"(ra)', '[rb] "s"(rb)', '[sa] "s"(sa)', '[sb] "s"(sb)',
-           '[drow] "v"(drow)', '[dkey] "v"(dkey)', '[pfoff] "v"(pfoff)', '[rpf] "s"(rpf)', '[klast] "s"(klast)']
-    clob = [f'"v{i}"' for i in range(119, 256)] + [f'"a{i}"' for i in range(128)] + ['"scc"', '"memory"']
+           '[drow] "v"(drow)', '[dkey] "v"(dkey)', '[pfoff] "v"(pfoff)', '[rpf] "s"(rpf)', '[klast] "s"(klast)', '[wave] "s"(wave_s)']
+    clob = [f'"v{i}"' for i in range(118, 256)] + [f'"a{i}"' for i in range(128)] + ['"scc"', '"memory"']
     print("        : " + ", ".join(outs) + " \\")
     print("        : " + ", ".join(ins) + " \\")
     print("        : " + ", ".join(clob) + ")")

@@ -571,12 +571,14 @@ def test_fused_epilogue(native, cuda, oracle, out_dtype, M):
 # 256x256 tile, one wave per SIMD, hand-scheduled K loop (FP8MI_KERNEL_GEMM_256W)
 # ---------------------------------------------------------------------------
 
-@pytest.mark.parametrize("M,K,N", [(256, 256, 256), (256, 384, 512), (512, 1024, 256), (768, 640, 1024), (256, 4096, 256)])
+@pytest.mark.parametrize("M,K,N", [(256, 256, 256), (256, 384, 512), (512, 1024, 256), (768, 640, 1024), (256, 4096, 256),
+                                   (300, 512, 256), (257, 384, 512), (129, 1024, 256), (1000, 640, 768), (1, 256, 256)])
 def test_gemm256w_parity_and_bits_of_the_ring_kernel(native, cuda, oracle, M, K, N):
     """The generated-assembly loop keeps the ring kernels' LDS image, fragment -> MFMA operand map and K order, so its
     result must equal the unsplit ring kernel's BIT FOR BIT (what makes a sharded linear equal the unsharded one does
     not depend on which tile kernel a shape lands on) and the oracle's within the matrix-core tolerance; every epilogue
-    form, both loop variants (the NaN redo runs the scrubbing loop) and K down to the two-step minimum."""
+    form, both loop variants (the NaN redo runs the scrubbing loop), K down to the two-step minimum, and any M: the rows
+    of a ragged last m-tile beyond M are read as zeros through the descriptor's range check and their stores dropped."""
     rng = np.random.default_rng(M + K + N)
     A = clean_bytes(rng, (M, K))
     B = clean_bytes(rng, (N, K))
@@ -606,14 +608,14 @@ def test_gemm256w_parity_and_bits_of_the_ring_kernel(native, cuda, oracle, M, K,
     both(scale_a=sM, scale_b=sN, bias=dev(bias_m, cuda), transposed_epilogue=True)
     both(scale_a=s1, scale_b=s1, transposed_epilogue=True, out_dtype=torch.bfloat16)
     # NaN bytes: reference semantics (decode to 0: the tile is redone with the scrubbing loop) and OCP propagation
-    A[3, 17] = 0x7F
+    A[min(3, M - 1), 17] = 0x7F
     B[N - 1, K - 1] = 0xFF
     tA, tB = dev(A, cuda), dev(B, cuda)
     check_mm(oracle, native, cuda, A, B, sa, sb, kernel=L.KERNEL_GEMM_256W, bias=bias)
     both(scale_a=sM, scale_b=sN, bias=dev(bias, cuda), out_dtype=torch.bfloat16)
     got = both(scale_a=s1, scale_b=s1, nan_mode=L.NAN_PROPAGATE).cpu().numpy()
     nan = np.isnan(got)
-    assert nan[3, :].all() and nan[:, N - 1].all() and nan.sum() == N + M - 1
+    assert nan[min(3, M - 1), :].all() and nan[:, N - 1].all() and nan.sum() == N + M - 1
 
 
 def test_gemm256w_envelope_dispatch_and_exactness(native, cuda, oracle):
@@ -622,7 +624,7 @@ def test_gemm256w_envelope_dispatch_and_exactness(native, cuda, oracle):
     so a wrong register or LDS address in the generated loop cannot hide behind the hardware tolerance; a padded row
     stride (lda, ldb, ldc > the row length) goes through the descriptors and the epilogue untouched."""
     z = torch.zeros
-    for (M, K, N) in ((255, 256, 256), (256, 256, 300), (256, 128, 256), (256, 272, 256)):
+    for (M, K, N) in ((256, 256, 300), (256, 128, 256), (256, 272, 256)):
         with pytest.raises(RuntimeError):
             native.fp8_scaled_mm(z(M, K, dtype=torch.uint8, device=cuda), z(N, K, dtype=torch.uint8, device=cuda), torch.ones(1),
                                  torch.ones(1), kernel=L.KERNEL_GEMM_256W)
@@ -650,6 +652,13 @@ def test_gemm256w_envelope_dispatch_and_exactness(native, cuda, oracle):
     native.fp8_scaled_mm(va, vb, s, s, kernel=L.KERNEL_GEMM_256W, out=vo)
     ref = native.fp8_scaled_mm(va.contiguous(), vb.contiguous(), s, s, kernel=L.KERNEL_GEMM_256, split_k=1)
     assert torch.equal(vo, ref) and bool((out[:, 512:] == -7.0).all())
+    # ragged M: the rows of the last m-tile beyond M are not written (canary rows behind the output)
+    big = torch.full((512, 256), -7.0, dtype=torch.bfloat16, device=cuda)
+    a3 = torch.randint(0, 0x7F, (300, 384), dtype=torch.uint8, device=cuda, generator=g)
+    b3 = torch.randint(0, 0x7F, (256, 384), dtype=torch.uint8, device=cuda, generator=g)
+    native.fp8_scaled_mm(a3, b3, s, s, kernel=L.KERNEL_GEMM_256W, out=big[:300], out_dtype=torch.bfloat16)
+    ref3 = native.fp8_scaled_mm(a3, b3, s, s, kernel=L.KERNEL_GEMM_256, split_k=1, out_dtype=torch.bfloat16)
+    assert torch.equal(big[:300], ref3) and bool((big[300:] == -7.0).all())
 
 
 @pytest.mark.parametrize("kernel", TILE_KERNELS)
