@@ -1,7 +1,7 @@
 // 256x256-tile FP8 e4m3fn GEMM with ONE wave per SIMD and a hand-scheduled K loop (gfx950).
 //
 // Same contract and the same bits as the ring kernels of fp8mi_gemm.hip (same LDS image, same fragment -> MFMA operand
-// map, K-steps added in order), for shapes of whole 256-column tiles and whole 128-byte K-steps (any M):
+// map, K-steps added in order), for shapes of whole 128-byte K-steps (any M, N):
 //
 //     C[m,n] = cast(((sum_k dec(A[m,k]) dec(B[n,k])) * sa[m] * sb[n] + bias[n]) * sr)        (fp8_matmul.metal:99-147)
 //
@@ -54,18 +54,19 @@ FP8MI_DEVICE TabRegs load_tables(const MMParams &p, int flags, int64_t m_wave, i
     // formed from scalars and one 32-bit min per lane (as 64-bit vector arithmetic its constants were hoisted and spilled)
     const int m_last = (int)p.M - 1, m_base = min((int)m_wave, m_last);   // (32-bit: M < 2^31, fp8mi_gemm256_supported)
     const int m_lim = max(min(m_last - m_base, 127), 0);
+    const int n_last = (int)p.N - 1, n_base = min((int)n_wave, n_last), n_lim = max(min(n_last - n_base, 127), 0);   // the same for columns
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int i = lane + 64 * h;
         t.sa[h] = p.scale_a[(flags & kFSaRow) ? m_base + min(i, m_lim) : 0];
-        t.sb[h] = p.scale_b[(flags & kFSbRow) ? n_wave + i : 0];
+        t.sb[h] = p.scale_b[(flags & kFSbRow) ? n_base + min(i, n_lim) : 0];
         t.bias[h] = 0u;
     }
     t.sr = 1.0f;
     if (flags & kFSr) t.sr = p.scale_result[0];
     if (flags & kFBias) {
-        const int64_t i0 = (flags & kFTransposed) ? m_base + min(lane, m_lim) : n_wave + lane;
-        const int64_t i1 = (flags & kFTransposed) ? m_base + min(lane + 64, m_lim) : n_wave + lane + 64;
+        const int64_t i0 = (flags & kFTransposed) ? m_base + min(lane, m_lim) : n_base + min(lane, n_lim);
+        const int64_t i1 = (flags & kFTransposed) ? m_base + min(lane + 64, m_lim) : n_base + min(lane + 64, n_lim);
         if (((flags >> kFBiasTypeShift) & 3) == FP8MI_F32) {
             t.bias[0] = ((const uint32_t *)p.bias)[i0];
             t.bias[1] = ((const uint32_t *)p.bias)[i1];
@@ -109,7 +110,7 @@ typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
 typedef __attribute__((address_space(1))) uint8_t glb_u8;
 
 template <int OUT, bool BIAS, bool TRANSPOSED, bool TABLES>
-FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave, int64_t n_wave, int64_t ldc, int rows_ok, int lane)
+FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave, int64_t n_wave, int64_t ldc, int rows_ok, int cols_ok, int lane)
 {
     constexpr int kEsz = OUT == FP8MI_F32 ? 4 : 2;
     constexpr int kBatch = 4;
@@ -173,10 +174,12 @@ FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8
         for (int b = 0; b < kBatch; ++b) {
             const int rr = (it0 + b) * 4 + rsub, r = rr & 15;
             const int col = (pp ^ (r >> 1)) * 8, row = half * 64 + rr;
-            const int off = (int)((uint32_t)row * ldc_b + (uint32_t)(col * kEsz));
+            // columns of a ragged last n-tile beyond N: the store's offset is pushed out of the descriptor's range (dropped)
+            const int off = col < cols_ok ? (int)((uint32_t)row * ldc_b + (uint32_t)(col * kEsz)) : 0x7FFFFFF0;
             if (OUT == FP8MI_F32) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[b][0], v[b][1], v[b][2], v[b][3]}), rc, off, 0, kNt);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[b][4], v[b][5], v[b][6], v[b][7]}), rc, off + 16, 0, kNt);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[b][4], v[b][5], v[b][6], v[b][7]}), rc,
+                                                       col + 4 < cols_ok ? off + 16 : 0x7FFFFFF0, 0, kNt);
             } else {
                 uint32_t w[4];
 #pragma unroll
@@ -200,29 +203,29 @@ FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8
 
 template <int OUT, bool TABLES>
 FP8MI_DEVICE f32x4 epilogue_half_flags(const MMParams &p, int flags, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave,
-                                       int64_t n_wave, int64_t ldc, int rows_ok, int lane)
+                                       int64_t n_wave, int64_t ldc, int rows_ok, int cols_ok, int lane)
 {
     if (!(flags & kFBias)) {
-        if (flags & kFTransposed) return epilogue_half<OUT, false, true, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane);
-        return epilogue_half<OUT, false, false, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane);
+        if (flags & kFTransposed) return epilogue_half<OUT, false, true, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
+        return epilogue_half<OUT, false, false, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
     }
-    if (flags & kFTransposed) return epilogue_half<OUT, true, true, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane);
-    return epilogue_half<OUT, true, false, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane);
+    if (flags & kFTransposed) return epilogue_half<OUT, true, true, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
+    return epilogue_half<OUT, true, false, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
 }
 
 FP8MI_DEVICE f32x4 epilogue_half_any(const MMParams &p, int flags, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave,
-                                     int64_t n_wave, int64_t ldc, int rows_ok, int lane)
+                                     int64_t n_wave, int64_t ldc, int rows_ok, int cols_ok, int lane)
 {
     const bool tables = (flags & (kFSaRow | kFSbRow)) != 0;
     const int od = (flags >> kFOutShift) & 3;
     if (od == FP8MI_F32)
-        return tables ? epilogue_half_flags<FP8MI_F32, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane)
-                      : epilogue_half_flags<FP8MI_F32, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane);
+        return tables ? epilogue_half_flags<FP8MI_F32, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane)
+                      : epilogue_half_flags<FP8MI_F32, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
     if (od == FP8MI_BF16)
-        return tables ? epilogue_half_flags<FP8MI_BF16, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane)
-                      : epilogue_half_flags<FP8MI_BF16, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane);
-    return tables ? epilogue_half_flags<FP8MI_F16, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane)
-                  : epilogue_half_flags<FP8MI_F16, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, lane);
+        return tables ? epilogue_half_flags<FP8MI_BF16, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane)
+                      : epilogue_half_flags<FP8MI_BF16, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
+    return tables ? epilogue_half_flags<FP8MI_F16, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane)
+                  : epilogue_half_flags<FP8MI_F16, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
 }
 
 #ifdef FP8MI_STAMP  // diagnostic build only: phase stamps of wave 0 of every workgroup (tools/stamp_gemm256.py)
@@ -265,7 +268,8 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
     // raw buffer descriptors (stride 0, range-checked) rebased to this tile's first row
     const uint64_t pa = (uint64_t)(p.A + m0 * p.lda), pb = (uint64_t)(p.B + n0 * p.ldb);
     const int64_t rows_a = min(kBM, (int)p.M - (int)m0);   // the last m-tile may be ragged: rows beyond M read as zeros (range check) and are not stored
-    const int64_t bytes_a = (rows_a - 1) * p.lda + p.K, bytes_b = (int64_t)(kBN - 1) * p.ldb + p.K;
+    const int64_t rows_b = min(kBN, (int)p.N - (int)n0);   // ... and so may the last n-tile
+    const int64_t bytes_a = (rows_a - 1) * p.lda + p.K, bytes_b = (rows_b - 1) * p.ldb + p.K;
     u32x4 ra = {(uint32_t)pa, (uint32_t)(pa >> 32) & 0xFFFFu, (uint32_t)min(bytes_a, (int64_t)0x7FFFFFFF), 0x00020000u};
     u32x4 rb = {(uint32_t)pb, (uint32_t)(pb >> 32) & 0xFFFFu, (uint32_t)min(bytes_b, (int64_t)0x7FFFFFFF), 0x00020000u};
     ra[0] = __builtin_amdgcn_readfirstlane(ra[0]); ra[1] = __builtin_amdgcn_readfirstlane(ra[1]);
@@ -316,8 +320,8 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
         constexpr bool kSplitPf = V >= 19 && V <= 21;
         uint32_t pfoff;
         if (!kSplitPf) {
-            pfoff = wave == 0 ? (uint32_t)((64 * (tile_m & 3) + lane_l) * p.ldb)
-                              : (wave == 1 && lane_l < 32 && 32 * (tile_n & 7) + lane_l < (int)rows_a) ? (uint32_t)((32 * (tile_n & 7) + lane_l) * p.lda) : kOOB;
+            pfoff = wave == 0 ? (uint32_t)((64 * (tile_m & 3) + lane_l) * p.ldb)   // (rows beyond a ragged tile's end: out of the descriptor's range, no access)
+                              : (wave == 1 && lane_l < 32) ? (uint32_t)((32 * (tile_n & 7) + lane_l) * p.lda) : kOOB;
         } else {
             pfoff = lane_l < 16 ? (uint32_t)((64 * (tile_m & 3) + 16 * wave + lane_l) * p.ldb) : kOOB;
         }
@@ -349,16 +353,17 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
         int fl = flags;        // (the switches and ldc too: their tests and multiples are then formed here, not in SGPRs held across the loop)
         int64_t ldc_e = p.ldc;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e), "+s"(m_wave), "+s"(n_wave), "+s"(fl), "+s"(ldc_e));
+        const int cols_ok = min(max((int)p.N - (int)n_wave, 0), 128);   // ... and columns (a multiple of the store width: fp8mi_gemm256_supported)
         const int rows_ok = min(max((int)p.M - (int)m_wave, 0), 128);   // valid rows of this wave's tile (ragged last m-tile)
         lds_cu8 *dump = (lds_cu8 *)(lds_void *)(smem + wave_e * kDumpWave);
         float *tabw = (float *)(smem + kTabBase + wave_e * kTabBytes);
         store_tables(fl, tabs, tabw, lane_e);
         lds_cf32 *tab = (lds_cf32 *)(lds_void *)tabw;
         const float sr = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tabw[512])));
-        f32x4 t = epilogue_half_any(p, fl, sr, dump, tab, 0, m_wave, n_wave, ldc_e, rows_ok, lane_e);
+        f32x4 t = epilogue_half_any(p, fl, sr, dump, tab, 0, m_wave, n_wave, ldc_e, rows_ok, cols_ok, lane_e);
         if (pass == 0) STAMP256(3);
         FP8MI_GEMM256_DUMP_HI();
-        t += epilogue_half_any(p, fl, sr, dump, tab, 1, m_wave, n_wave, ldc_e, rows_ok, lane_e);
+        t += epilogue_half_any(p, fl, sr, dump, tab, 1, m_wave, n_wave, ldc_e, rows_ok, cols_ok, lane_e);
         if (!(flags & kFNanZero) || pass == 1) break;
         const float sum = (t[0] + t[1]) + (t[2] + t[3]);
         if (sum != sum) *flag = 1;
@@ -376,12 +381,13 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
 
 }  // namespace
 
-// whole 256-column tiles (any M: the last m-tile may be ragged), whole K-steps (at least two), rows the vector epilogue can store, no split-K
+// any M and N (ragged last tiles; N a multiple of the 16-byte store: 4 fp32 / 8 half columns), whole K-steps (at least two), 16-byte
+// aligned output rows, no split-K
 bool fp8mi_gemm256_supported(const MMParams &p)
 {
     const int esz = p.out_dtype == FP8MI_F32 ? 4 : 2;
-    return fp8mi_gemm_supported(p) && p.M < 0x7FFFFF00 && (p.N % kBN) == 0 && (p.K % BK) == 0 && p.K >= 2 * BK && p.split <= 1 &&
-           ((p.ldc * esz) % 16) == 0 && (((uintptr_t)p.C) % 16) == 0 && ((p.M + kBM - 1) / kBM) * (p.N / kBN) <= 0x7FFFFFFF &&
+    return fp8mi_gemm_supported(p) && p.M < 0x7FFFFF00 && p.N < 0x7FFFFF00 && (p.N % (16 / esz)) == 0 && (p.K % BK) == 0 && p.K >= 2 * BK && p.split <= 1 &&
+           ((p.ldc * esz) % 16) == 0 && (((uintptr_t)p.C) % 16) == 0 && ((p.M + kBM - 1) / kBM) * ((p.N + kBN - 1) / kBN) <= 0x7FFFFFFF &&
            p.ldc * esz * 128 < 0x7FFF0000;   // the epilogue addresses a wave tile (128 rows) with 32-bit offsets
 }
 
@@ -394,7 +400,7 @@ extern "C" int fp8mi_debug_read_stamps256(unsigned long long *out, int n)
 
 int fp8mi_launch_gemm256(const MMParams &p, int variant, hipStream_t s)
 {
-    const int64_t tm = (p.M + kBM - 1) / kBM, tn = p.N / kBN;
+    const int64_t tm = (p.M + kBM - 1) / kBM, tn = (p.N + kBN - 1) / kBN;
     const unsigned grid = (unsigned)(tm * tn);
     switch (variant) {
     case 0: return fp8mi_launch(gemm256_kernel<0>, dim3(grid), dim3(kThreads256), s, p, (int)tm, (int)tn, (int)grid);

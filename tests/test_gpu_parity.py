@@ -572,13 +572,14 @@ def test_fused_epilogue(native, cuda, oracle, out_dtype, M):
 # ---------------------------------------------------------------------------
 
 @pytest.mark.parametrize("M,K,N", [(256, 256, 256), (256, 384, 512), (512, 1024, 256), (768, 640, 1024), (256, 4096, 256),
-                                   (300, 512, 256), (257, 384, 512), (129, 1024, 256), (1000, 640, 768), (1, 256, 256)])
+                                   (300, 512, 256), (257, 384, 512), (129, 1024, 256), (1000, 640, 768), (1, 256, 256),
+                                   (256, 384, 264), (512, 512, 1000), (300, 640, 520), (64, 1024, 8)])
 def test_gemm256w_parity_and_bits_of_the_ring_kernel(native, cuda, oracle, M, K, N):
     """The generated-assembly loop keeps the ring kernels' LDS image, fragment -> MFMA operand map and K order, so its
     result must equal the unsplit ring kernel's BIT FOR BIT (what makes a sharded linear equal the unsharded one does
     not depend on which tile kernel a shape lands on) and the oracle's within the matrix-core tolerance; every epilogue
     form, both loop variants (the NaN redo runs the scrubbing loop), K down to the two-step minimum, and any M: the rows
-    of a ragged last m-tile beyond M are read as zeros through the descriptor's range check and their stores dropped."""
+    / columns of ragged last tiles are read as zeros through the descriptors' range checks and their stores dropped."""
     rng = np.random.default_rng(M + K + N)
     A = clean_bytes(rng, (M, K))
     B = clean_bytes(rng, (N, K))
@@ -624,7 +625,7 @@ def test_gemm256w_envelope_dispatch_and_exactness(native, cuda, oracle):
     so a wrong register or LDS address in the generated loop cannot hide behind the hardware tolerance; a padded row
     stride (lda, ldb, ldc > the row length) goes through the descriptors and the epilogue untouched."""
     z = torch.zeros
-    for (M, K, N) in ((256, 256, 300), (256, 128, 256), (256, 272, 256)):
+    for (M, K, N) in ((256, 256, 301), (256, 128, 256), (256, 272, 256)):
         with pytest.raises(RuntimeError):
             native.fp8_scaled_mm(z(M, K, dtype=torch.uint8, device=cuda), z(N, K, dtype=torch.uint8, device=cuda), torch.ones(1),
                                  torch.ones(1), kernel=L.KERNEL_GEMM_256W)
@@ -659,6 +660,14 @@ def test_gemm256w_envelope_dispatch_and_exactness(native, cuda, oracle):
     native.fp8_scaled_mm(a3, b3, s, s, kernel=L.KERNEL_GEMM_256W, out=big[:300], out_dtype=torch.bfloat16)
     ref3 = native.fp8_scaled_mm(a3, b3, s, s, kernel=L.KERNEL_GEMM_256, split_k=1, out_dtype=torch.bfloat16)
     assert torch.equal(big[:300], ref3) and bool((big[300:] == -7.0).all())
+    # ragged N inside a wider buffer: the columns beyond N keep the canary
+    wide = torch.full((300, 512), -7.0, dtype=torch.bfloat16, device=cuda)
+    b4 = torch.randint(0, 0x7F, (264, 384), dtype=torch.uint8, device=cuda, generator=g)
+    native.fp8_scaled_mm(a3, b4, s, s, kernel=L.KERNEL_GEMM_256W, out=wide[:, :264], out_dtype=torch.bfloat16)
+    ref4 = native.fp8_scaled_mm(a3, b4, s, s, kernel=L.KERNEL_GEMM_256, split_k=1, out_dtype=torch.bfloat16)
+    assert torch.equal(wide[:, :264], ref4) and bool((wide[:, 264:] == -7.0).all())
+    with pytest.raises(RuntimeError):   # 16-bit rows are stored 8 columns at a time
+        native.fp8_scaled_mm(a3, torch.zeros(260, 384, dtype=torch.uint8, device=cuda), s, s, kernel=L.KERNEL_GEMM_256W, out_dtype=torch.bfloat16)
 
 
 @pytest.mark.parametrize("kernel", TILE_KERNELS)

@@ -10,7 +10,8 @@ dev = torch.device("cuda:0")
 KID = int(sys.argv[1]) if len(sys.argv) > 1 else L.KERNEL_GEMM_256W   # a schedule variant of the diagnostic library: 80 + variant
 worst = 0.0
 for (M, K, N) in ((256, 256, 256), (256, 384, 512), (512, 1024, 256), (768, 640, 1024), (256, 4096, 256), (1024, 3072, 2048),
-                  (300, 512, 256), (257, 384, 512), (1, 256, 256), (1000, 640, 768), (129, 1024, 256), (2049, 256, 512)):   # ragged M: last m-tile partly / one wave tile empty
+                  (300, 512, 256), (257, 384, 512), (1, 256, 256), (1000, 640, 768), (129, 1024, 256), (2049, 256, 512),
+                  (256, 384, 264), (512, 512, 1000), (300, 640, 520), (64, 1024, 8), (515, 256, 776)):   # ragged N too (a multiple of 8)   # ragged M: last m-tile partly / one wave tile empty
     rng = np.random.default_rng(M + K + N)
     for nan in (False, True):
         A = rng.integers(0, 256, size=(M, K), dtype=np.uint8); B = rng.integers(0, 256, size=(N, K), dtype=np.uint8)
