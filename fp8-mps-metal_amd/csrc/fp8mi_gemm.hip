@@ -582,7 +582,7 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
         const double t256 = (double)(((p.M + 255) / 256) * ((p.N + 255) / 256));
         const double t128 = (double)(((p.M + 127) / 128) * ((p.N + 127) / 128));
         const double t64 = (double)(((p.M + 127) / 128) * ((p.N + 63) / 64));
-        // whole 256x256 tiles and K-steps run on the hand-scheduled one-wave-per-SIMD kernel (fp8mi_gemm256.hip): 8.5 + 1.35 nk per
+        // shapes of whole K-steps run on the hand-scheduled one-wave-per-SIMD kernel (fp8mi_gemm256.hip; any M, N): 8.5 + 1.35 nk per
         // round (FLUX: 40.8 us per tile at nk = 24, in-kernel stamps) against 8 + 1.6 nk for the ring kernel
         const bool w256 = fp8mi_gemm256_supported(p);
         const double us256 = rounds(t256, cus, 0.75, 0.25) * (w256 ? 8.5 + 1.35 * nk : 8.0 + 1.6 * nk);  // (a quarter-filled round of 256x256

@@ -8,7 +8,8 @@ next to 128 fragment VGPRs without shuffling them.  The loop is 
 physical registers:
 
     a[0:255]     accumulators, a[(tm * 8 + tn) * 4 + j]   (W fragment tn = MFMA operand A, X fragment tm = operand B)
-    v[120:127]   LDS addresses of the accumulator dump
+    v[120:127]   LDS addresses of the accumulator dump;  v119 landing register of the L2 prefetch loads (never read);
+    v118         running source offset of the stage DMA (row part: range-checked by the buffer descriptor, see dma_block)
 
 The accumulators leave through the LDS: behind the last MFMA and a barrier (the ring is idle then) the loop writes fragment
 rows tm = 0..3 of every wave into the wave's 32-KiB quarter of the ring as plain fp32 rows (16 rows x 512 B per fragment

@@ -619,6 +619,29 @@ def test_gemm256w_parity_and_bits_of_the_ring_kernel(native, cuda, oracle, M, K,
     assert nan[min(3, M - 1), :].all() and nan[:, N - 1].all() and nan.sum() == N + M - 1
 
 
+def test_gemm256w_random_shapes(native, cuda, oracle):
+    """Seeded random shapes inside the kernel's envelope (any M, N a multiple of 8, K a multiple of 128) with random
+    epilogue forms, forced through the 256W kernel: oracle tolerance and the ring kernel's bits."""
+    rng = np.random.default_rng(2026)
+    for _ in range(10):
+        M = int(rng.integers(1, 1100))
+        N = 8 * int(rng.integers(1, 140))
+        K = 128 * int(rng.integers(2, 12))
+        A = clean_bytes(rng, (M, K))
+        B = clean_bytes(rng, (N, K))
+        sa = rng.uniform(0.005, 0.02, size=M).astype(np.float32) if rng.integers(2) else np.array([0.01], np.float32)
+        sb = rng.uniform(0.005, 0.02, size=N).astype(np.float32) if rng.integers(2) else np.array([0.02], np.float32)
+        bias = rng.standard_normal(N).astype(np.float32) if rng.integers(2) else None
+        od = [torch.float32, torch.bfloat16, torch.float16][int(rng.integers(3))]
+        if rng.integers(4) == 0:
+            A[int(rng.integers(M)), int(rng.integers(K))] = 0x7F   # a NaN byte: the scrubbing redo
+        got = check_mm(oracle, native, cuda, A, B, sa, sb, kernel=L.KERNEL_GEMM_256W, bias=bias, out_dtype=od)
+        kw = {"bias": dev(bias, cuda)} if bias is not None else {}
+        ref = native.fp8_scaled_mm(dev(A, cuda), dev(B, cuda), dev(sa, cuda), dev(sb, cuda), out_dtype=od, kernel=L.KERNEL_GEMM_256,
+                                   split_k=1, **kw)
+        assert torch.equal(got, ref), (M, K, N, od)
+
+
 def test_gemm256w_envelope_dispatch_and_exactness(native, cuda, oracle):
     """Outside whole tiles / K-steps the explicit id refuses and AUTO falls back to the ring kernels; inside, AUTO picks it
     for large shapes (same bits either way); operands within a 2^12 product range are summed exactly by the matrix core,
