@@ -157,6 +157,7 @@ struct StagePlan {
     bool full;          // interior tile: no row masking
     uint32_t pf_off;    // C::PFD: this lane's line of the B panel's share to prefetch (kOOB: none)
     u32x4 pf_rsrc;      // ... and the B panel's descriptor as plain words (an asm operand)
+    int pf_waves;       // how many waves prefetch (1 when the panel has 4 readers on the XCD, 2 with 2, 0 when this tile is its only reader)
 };
 
 template <typename C, bool TAIL>
@@ -263,7 +264,7 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
     auto next_ks = [&]() { const int r = ks; ks = (ks + 1 == nk) ? 0 : ks + 1; return ks0 + r; };
     uint32_t sink = 0;  // C::PFD: landing register of the L2 prefetch loads (never read)
     auto prefetch = [&](int stage) {  // stage relative to ks0, clamped to this workgroup's last one
-        if (C::PFD > 0 && wave == 0) prefetch_stage(sink, pl.pf_off, pl.pf_rsrc, (uint32_t)((ks0 + min(stage, nk - 1)) * (BK * C::KS)));
+        if (C::PFD > 0 && wave < pl.pf_waves) prefetch_stage(sink, pl.pf_off, pl.pf_rsrc, (uint32_t)((ks0 + min(stage, nk - 1)) * (BK * C::KS)));
     };
 
     // prologue: PF stages in flight (stage s -> ring slot s)
@@ -461,11 +462,18 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThr
         pl.rows_b = (int)rows_b;
         pl.full = rows_a == BM && rows_b == BN;
         pl.pf_off = kOOB;
+        pl.pf_waves = 0;
         if (C::PFD > 0) {
             // this tile's quarter of its B panel's lines for one stage (B has 4 readers on the XCD: the m-tiles of its group)
             constexpr int kLines = BN * C::KS / 4;
             static_assert(C::PFD == 0 || kLines <= 64, "one prefetch instruction per stage");
-            const int li = (tile_m & 3) * kLines + lane, prow = li / C::KS, pk = li % C::KS;
+            // readers of this B panel on the XCD = the m-tiles of this tile's group (4, fewer in a short last group): with 4 readers
+            // wave 0 of each warms one quarter, with 2 readers waves 0-1 of each.  A tile that is its panel's only reader does not
+            // prefetch: warming its own lines only adds requests (decode shape M=64 K=14336 N=4096: 18.6 -> 20.5 us, measured)
+            const int gm = min(4, tiles_m - (tile_m & ~3)), nshare = gm >= 4 ? 4 : (gm >= 2 ? 2 : 1);
+            pl.pf_waves = nshare == 1 ? 0 : 4 / nshare;
+            const int quarter = (tile_m % nshare) * (4 / nshare) + wave;
+            const int li = (quarter & 3) * kLines + lane, prow = li / C::KS, pk = li % C::KS;
             if (lane < kLines && prow < (int)rows_b && (p.K % (BK * C::KS)) == 0) pl.pf_off = (uint32_t)(prow * p.ldb + pk * BK);
             const uint64_t pb = (uint64_t)(p.B + n0 * p.ldb);
             pl.pf_rsrc = u32x4{(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pb),
