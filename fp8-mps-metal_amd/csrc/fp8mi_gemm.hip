@@ -596,11 +596,16 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
         const double us256 = rounds(t256, cus, 0.75, 0.25) * (w256 ? 8.5 + 1.35 * nk : 8.0 + 1.6 * nk);  // (a quarter-filled round of 256x256
         const double us128 = rounds(t128, 2 * cus, 0.55, 0.45) * (5.5 + 0.87 * nk);  //  tiles still costs 0.8 of a full one)
         const double us64 = rounds(t64, cus, 0.6, 0.4) * (5.0 + 0.37 * nk);
+        // ... and its 256x128 form at 1.5 + 0.89 nk per round, a partly filled round costing nearly a full one (fitted:
+        // 2048x4096x4096 29.8 us, 1024x8192x8192 58.5, 4096x3072x1536 23.3, 3072^3 45.6, FLUX 136.8; profiles/r02_large_shapes.txt)
+        const double t256n = (double)(((p.M + 255) / 256) * ((p.N + 127) / 128));
+        const double us256n = w256 ? rounds(t256n, cus, 0.85, 0.15) * (1.5 + 0.89 * nk) : 1e30;
         if (t64 <= cus / 2) {
             // few tiles: one per CU at most, split-K (launch<>) fills the rest of the chip when a workspace came along;
             // with few rows of A the tile is better spent on N
             variant = (p.M <= 64 && p.ws && p.split != 1) ? FP8MI_KERNEL_GEMM_64x128 : FP8MI_KERNEL_GEMM_128x64;
-        } else if (us256 <= us128 && us256 <= us64) variant = w256 ? FP8MI_KERNEL_GEMM_256W : FP8MI_KERNEL_GEMM_256;
+        } else if (us256n < us256 && us256n < us128 && us256n < us64) variant = FP8MI_KERNEL_GEMM_256x128W;
+        else if (us256 <= us128 && us256 <= us64) variant = w256 ? FP8MI_KERNEL_GEMM_256W : FP8MI_KERNEL_GEMM_256;
         else if (us128 <= us64) variant = FP8MI_KERNEL_GEMM_128;
         else variant = FP8MI_KERNEL_GEMM_128x64;
     }
@@ -614,6 +619,7 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     case FP8MI_KERNEL_GEMM_256: return launch<256, 256, 128, 64, 2, 2, 0, 1, 4>(p, s);   // 2 x 64 KiB ring, staggered wave groups
     case FP8MI_KERNEL_GEMM_64x128: return launch<64, 128, 32, 32, 3, 1, 0, 2, 4>(p, s);  // 3 x 48 KiB ring, for M <= 64
     case FP8MI_KERNEL_GEMM_256W: return fp8mi_launch_gemm256(p, 0, s);                   // (only chosen above when fp8mi_gemm256_supported)
+    case FP8MI_KERNEL_GEMM_256x128W: return fp8mi_launch_gemm256(p, 1000, s);
 #ifdef FP8MI_DIAG  // schedule variants kept for A/B timing (diagnostic library only; same results): tools/ab_kernels.py
     case 30: return launch<256, 256, 128, 64, 2, 1, 0, 1, 4>(p, s);            // 256x256, fragment reads before the stage DMA
     case 31: return launch<128, 128, 64, 32, 2, 1, 0, 1, 4>(p, s);             // 128x128, same

@@ -21,12 +21,19 @@
 
 namespace {
 
-constexpr int kBM = 256, kBN = 256, kThreads256 = 256;   // 4 waves, one per SIMD
-constexpr int kSlotBytes = (kBM + kBN) * BK;   // 64 KiB: A's 256 rows, then B's
-constexpr int kRing256 = 2 * kSlotBytes;
-typedef float f32x32 __attribute__((ext_vector_type(32)));   // one fragment row of accumulators (asm operand type)
-constexpr int kDumpWave = 32 * 1024;   // a wave's quarter of the ring: 4 fragment rows x (16 rows x 512 B) of fp32 accumulators
-constexpr int kDumpRow = 8 * 1024;     // one fragment row
+constexpr int kBM = 256, kThreads256 = 256;   // 4 waves, one per SIMD
+typedef float f32x32 __attribute__((ext_vector_type(32)));   // 32 accumulators (asm operand type)
+// Two workgroup tiles share everything but the wave tile's width: BN = 256 (wave 128x128, 64 MFMAs per K-step: the matrix-bound
+// shape) and BN = 128 (wave 128x64, 32 MFMAs per step, 48-KiB stages: for shapes that give 256x256 tiles less than a round).
+template <int BN>
+struct Geo {
+    static constexpr int kSlotBytes = (kBM + BN) * BK;   // one K-step: A's 256 rows, then B's
+    static constexpr int kRing = 2 * kSlotBytes;
+    static constexpr int kCols = BN / 2;                 // columns of a wave tile
+    static constexpr int kDumpRow = 16 * kCols * 4;      // one fragment row of the accumulator dump (16 rows of fp32)
+    static constexpr int kDumpWave = 4 * kDumpRow;       // a wave's share of the ring: 4 fragment rows
+    static constexpr int kTabBase = kRing + kFlagBytes;
+};
 
 // The epilogue's rounding sequence is the ring kernels': (acc * sa) * sb, + bias, * sr - four roundings.  With the
 // switches as template parameters hipcc would contract the multiply-add into an fma (one rounding less, different bits).
@@ -37,7 +44,6 @@ constexpr int kDumpRow = 8 * 1024;     // one fragment row
 // at kernel entry (loads in flight under the K loop, uniform type switches out of the epilogue's inner loop) and writes
 // them to the LDS after the loop.
 constexpr int kTabBytes = 4 * 512 + 16;                  // per wave: four 128-entry tables, then scale_result
-constexpr int kTabBase = kRing256 + kFlagBytes;
 // the launch's uniform switches packed into one SGPR (ten separate fields kept alive across the tile loop ran hipcc out of SGPRs:
 // it parked booleans in VGPRs, spilled those to scratch and reloaded them - with a full vmcnt wait - in front of the K loop)
 enum { kFBias = 1, kFTransposed = 2, kFSaRow = 4, kFSbRow = 8, kFNanZero = 16, kFSr = 32, kFOutShift = 6, kFBiasTypeShift = 8 };
@@ -47,14 +53,14 @@ struct TabRegs {       // as loaded: nothing here is USED before the K loop (a u
     uint32_t bias[2];  // raw fp32 bits, or a zero-extended 16-bit pattern
 };
 
-FP8MI_DEVICE TabRegs load_tables(const MMParams &p, int flags, int64_t m_wave, int64_t n_wave, int lane)
+FP8MI_DEVICE TabRegs load_tables(const MMParams &p, int flags, int64_t m_wave, int64_t n_wave, int cols, int lane)
 {
     TabRegs t;
     // rows of a ragged last m-tile beyond M take the entry of row M - 1 (any valid address: they are never stored); the clamp is
     // formed from scalars and one 32-bit min per lane (as 64-bit vector arithmetic its constants were hoisted and spilled)
     const int m_last = (int)p.M - 1, m_base = min((int)m_wave, m_last);   // (32-bit: M < 2^31, fp8mi_gemm256_supported)
     const int m_lim = max(min(m_last - m_base, 127), 0);
-    const int n_last = (int)p.N - 1, n_base = min((int)n_wave, n_last), n_lim = max(min(n_last - n_base, 127), 0);   // the same for columns
+    const int n_last = (int)p.N - 1, n_base = min((int)n_wave, n_last), n_lim = max(min(n_last - n_base, cols - 1), 0);   // the same for columns
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int i = lane + 64 * h;
@@ -109,12 +115,14 @@ typedef __attribute__((address_space(3))) const float lds_cf32;
 typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
 typedef __attribute__((address_space(1))) uint8_t glb_u8;
 
-template <int OUT, bool BIAS, bool TRANSPOSED, bool TABLES>
+template <int COLS, int OUT, bool BIAS, bool TRANSPOSED, bool TABLES>
 FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave, int64_t n_wave, int64_t ldc, int rows_ok, int cols_ok, int lane)
 {
     constexpr int kEsz = OUT == FP8MI_F32 ? 4 : 2;
     constexpr int kBatch = 4;
-    const int pp = lane & 15, rsub = lane >> 4;
+    constexpr int kLpr = COLS / 8, kRpi = 64 / kLpr, kIters = 64 / kRpi;   // lanes per row, rows per instruction, instructions per half
+    constexpr int kDumpRow = 16 * COLS * 4;
+    const int pp = lane % kLpr, rsub = lane / kLpr;
     // the wave tile of C as a raw buffer: 32-bit offsets in the store instead of 64-bit pointer arithmetic per row
     // (num_records = the wave tile's valid rows: stores to rows of a ragged last m-tile beyond M are out of range and dropped)
     __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)((uint8_t *)p.C + (m_wave * ldc + n_wave) * kEsz), 0,
@@ -127,17 +135,17 @@ FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8
     // two batches per trip where registers allow: the LDS reads of the second are scheduled above the arithmetic of the first
     constexpr int kUnroll = (TABLES || BIAS) ? 1 : 2;
 #pragma unroll kUnroll
-    for (int it0 = 0; it0 < 16; it0 += kBatch) {
+    for (int it0 = 0; it0 < kIters; it0 += kBatch) {
         f32x4 q0[kBatch], q1[kBatch], sb0[kBatch], sb1[kBatch], bn0[kBatch], bn1[kBatch];
         float sa[kBatch], bm[kBatch];
 #pragma unroll
         for (int b = 0; b < kBatch; ++b) {
-            const int rr = (it0 + b) * 4 + rsub, r = rr & 15;   // row inside the half: fragment row rr >> 4, row r
-            lds_cu8 *src = dump + (rr >> 4) * kDumpRow + r * 512 + pp * 32;
+            const int rr = (it0 + b) * kRpi + rsub, r = rr & 15;   // row inside the half: fragment row rr >> 4, row r
+            lds_cu8 *src = dump + (rr >> 4) * kDumpRow + r * (COLS * 4) + pp * 32;
             const int swap = (r & 1) * 16;                      // odd rows hold the pair's chunks exchanged: undo it in the address
             q0[b] = *(lds_cf32x4 *)(src + swap);
             q1[b] = *(lds_cf32x4 *)(src + (16 - swap));
-            const int col = (pp ^ (r >> 1)) * 8, row = half * 64 + rr;
+            const int col = ((pp ^ (r >> 1)) & (kLpr - 1)) * 8, row = half * 64 + rr;
             if (TABLES) {
                 sa[b] = tab[row];
                 sb0[b] = *(lds_cf32x4 *)(tab + 128 + col);
@@ -172,8 +180,8 @@ FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8
         }
 #pragma unroll
         for (int b = 0; b < kBatch; ++b) {
-            const int rr = (it0 + b) * 4 + rsub, r = rr & 15;
-            const int col = (pp ^ (r >> 1)) * 8, row = half * 64 + rr;
+            const int rr = (it0 + b) * kRpi + rsub, r = rr & 15;
+            const int col = ((pp ^ (r >> 1)) & (kLpr - 1)) * 8, row = half * 64 + rr;
             // columns of a ragged last n-tile beyond N: the store's offset is pushed out of the descriptor's range (dropped)
             const int off = col < cols_ok ? (int)((uint32_t)row * ldc_b + (uint32_t)(col * kEsz)) : 0x7FFFFFF0;
             if (OUT == FP8MI_F32) {
@@ -201,31 +209,32 @@ FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8
     return nan_sum;
 }
 
-template <int OUT, bool TABLES>
+template <int COLS, int OUT, bool TABLES>
 FP8MI_DEVICE f32x4 epilogue_half_flags(const MMParams &p, int flags, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave,
                                        int64_t n_wave, int64_t ldc, int rows_ok, int cols_ok, int lane)
 {
     if (!(flags & kFBias)) {
-        if (flags & kFTransposed) return epilogue_half<OUT, false, true, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
-        return epilogue_half<OUT, false, false, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
+        if (flags & kFTransposed) return epilogue_half<COLS, OUT, false, true, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
+        return epilogue_half<COLS, OUT, false, false, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
     }
-    if (flags & kFTransposed) return epilogue_half<OUT, true, true, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
-    return epilogue_half<OUT, true, false, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
+    if (flags & kFTransposed) return epilogue_half<COLS, OUT, true, true, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
+    return epilogue_half<COLS, OUT, true, false, TABLES>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
 }
 
+template <int COLS>
 FP8MI_DEVICE f32x4 epilogue_half_any(const MMParams &p, int flags, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave,
                                      int64_t n_wave, int64_t ldc, int rows_ok, int cols_ok, int lane)
 {
     const bool tables = (flags & (kFSaRow | kFSbRow)) != 0;
     const int od = (flags >> kFOutShift) & 3;
     if (od == FP8MI_F32)
-        return tables ? epilogue_half_flags<FP8MI_F32, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane)
-                      : epilogue_half_flags<FP8MI_F32, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
+        return tables ? epilogue_half_flags<COLS, FP8MI_F32, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane)
+                      : epilogue_half_flags<COLS, FP8MI_F32, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
     if (od == FP8MI_BF16)
-        return tables ? epilogue_half_flags<FP8MI_BF16, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane)
-                      : epilogue_half_flags<FP8MI_BF16, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
-    return tables ? epilogue_half_flags<FP8MI_F16, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane)
-                  : epilogue_half_flags<FP8MI_F16, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
+        return tables ? epilogue_half_flags<COLS, FP8MI_BF16, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane)
+                      : epilogue_half_flags<COLS, FP8MI_BF16, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
+    return tables ? epilogue_half_flags<COLS, FP8MI_F16, true>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane)
+                  : epilogue_half_flags<COLS, FP8MI_F16, false>(p, flags, sr, dump, tab, half, m_wave, n_wave, ldc, rows_ok, cols_ok, lane);
 }
 
 #ifdef FP8MI_STAMP  // diagnostic build only: phase stamps of wave 0 of every workgroup (tools/stamp_gemm256.py)
@@ -240,7 +249,7 @@ __device__ unsigned long long g_stamp256[1024 * 8];
 #define STAMP256(i) do { } while (0)
 #endif
 
-template <int V>   // V = 0: the product schedule; others only in the diagnostic build (gen_gemm256_loop.py VARIANTS)
+template <int V, int BN>   // V = 0: the product schedule; others only in the diagnostic build (gen_gemm256_loop.py VARIANTS, BN = 256)
 __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int tiles_m, int tiles_n, int nwg)
 {
 #ifdef FP8MI_STAMP
@@ -252,6 +261,8 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
     int flags = (p.bias ? kFBias : 0) | (p.transposed ? kFTransposed : 0) | (p.sa_row ? kFSaRow : 0) | (p.sb_row ? kFSbRow : 0) |
                 (p.nan_zero ? kFNanZero : 0) | (p.scale_result ? kFSr : 0) | (p.out_dtype << kFOutShift) | (p.bias_dtype << kFBiasTypeShift);
     FP8MI_PIN_S(flags);
+    using G = Geo<BN>;
+    constexpr int kBN = BN, kSlotBytes = G::kSlotBytes, kRing256 = G::kRing, kDumpWave = G::kDumpWave, kTabBase = G::kTabBase;
     __shared__ __attribute__((aligned(16))) uint8_t smem[kRing256 + kFlagBytes + 4 * kTabBytes];
     if (threadIdx.x == 0) *(__attribute__((address_space(3))) volatile int *)(lds_void *)(smem + kRing256) = 0;  // NaN verdict word (ordered by the K loop's barriers)
 
@@ -297,8 +308,8 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
         int fl_l = flags;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_l), "+s"(fl_l));
         const int wave = FP8MI_SIMD_ID();
-        const int wm0 = (wave & 1) * 128, wn0 = (wave >> 1) * 128;
-        const TabRegs tabs = load_tables(p, fl_l, m0 + wm0, n0 + wn0, lane_l);   // in flight under the K loop, stored to the LDS behind it
+        const int wm0 = (wave & 1) * 128, wn0 = (wave >> 1) * G::kCols;
+        const TabRegs tabs = load_tables(p, fl_l, m0 + wm0, n0 + wn0, G::kCols, lane_l);   // in flight under the K loop, stored to the LDS behind it
         // staging plan (fp8mi_gemm.hip): wave w stages the 1-KiB groups w, w + 4, ... of both operands; lane -> (row, swizzled chunk)
         const int row0 = wave * 8 + (lane_l >> 3);
         const int chunk = (lane_l & 7) ^ (((wave & 1) * 4 + (lane_l >> 4)) & 7);
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
         constexpr bool kSplitPf = V >= 19 && V <= 21;
         uint32_t pfoff;
         if (!kSplitPf) {
-            pfoff = wave == 0 ? (uint32_t)((64 * (tile_m & 3) + lane_l) * p.ldb)   // (rows beyond a ragged tile's end: out of the descriptor's range, no access)
+            pfoff = (wave == 0 && lane_l < BN / 4) ? (uint32_t)((BN / 4 * (tile_m & 3) + lane_l) * p.ldb)   // (rows beyond a ragged tile's end: out of the descriptor's range, no access)
                               : (wave == 1 && lane_l < 32) ? (uint32_t)((32 * (tile_n & 7) + lane_l) * p.lda) : kOOB;
         } else {
             pfoff = lane_l < 16 ? (uint32_t)((64 * (tile_m & 3) + 16 * wave + lane_l) * p.ldb) : kOOB;
@@ -329,10 +340,12 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
         const u32x4 rpf = (kSplitPf || wave == 0) ? rb : ra;   // (the split variants prefetch B lines only: the A panel is re-read 48x and stays in the L2)
         const uint32_t klast = (uint32_t)((nk - 1) * BK);
         // accumulator dump (gen_gemm256_loop.py): row fr of each fragment row, 16-byte chunk (4 tn + fg) ^ fr
-        const uint32_t drow = lds0 + wave * kDumpWave + fr * 512, dkey = (uint32_t)((fg ^ fr) << 4);
-        f32x32 acc4, acc5, acc6, acc7;   // fragment rows 4..7, pinned to a[128:255] by the asm
+        const uint32_t drow = lds0 + wave * kDumpWave + fr * (G::kCols * 4), dkey = (uint32_t)((fg ^ fr) << 4);
+        f32x32 acc4, acc5, acc6, acc7;   // fragment rows 4..7, pinned by the asm to a[128:255] (BN = 256) / a[64:127] (BN = 128: acc4, acc5)
         if (pass == 0) {
-            if constexpr (V == 0) {
+            if constexpr (BN == 128) {
+                FP8MI_GEMM256_LOOP_N128();
+            } else if constexpr (V == 0) {
                 FP8MI_GEMM256_LOOP();
             }
 #ifdef FP8MI_DIAG
@@ -342,28 +355,37 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
 #endif
         } else {
             uint32_t vt0, vt1;
-            FP8MI_GEMM256_LOOP_SCRUB();
+            if constexpr (BN == 128) {
+                FP8MI_GEMM256_LOOP_SCRUB_N128();
+            } else {
+                FP8MI_GEMM256_LOOP_SCRUB();
+            }
             (void)vt0; (void)vt1;
         }
         (void)t0; (void)t1;
         if (pass == 0) STAMP256(2);
         int lane_e;
         const int wave_e = FP8MI_SIMD_ID();   // (read again: nothing of the wave's identity is kept across the K loop)
-        int64_t m_wave = m0 + (wave_e & 1) * 128, n_wave = n0 + (wave_e >> 1) * 128;
+        int64_t m_wave = m0 + (wave_e & 1) * 128, n_wave = n0 + (wave_e >> 1) * G::kCols;
         int fl = flags;        // (the switches and ldc too: their tests and multiples are then formed here, not in SGPRs held across the loop)
         int64_t ldc_e = p.ldc;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e), "+s"(m_wave), "+s"(n_wave), "+s"(fl), "+s"(ldc_e));
-        const int cols_ok = min(max((int)p.N - (int)n_wave, 0), 128);   // ... and columns (a multiple of the store width: fp8mi_gemm256_supported)
+        const int cols_ok = min(max((int)p.N - (int)n_wave, 0), G::kCols);   // ... and columns (a multiple of the store width: fp8mi_gemm256_supported)
         const int rows_ok = min(max((int)p.M - (int)m_wave, 0), 128);   // valid rows of this wave's tile (ragged last m-tile)
         lds_cu8 *dump = (lds_cu8 *)(lds_void *)(smem + wave_e * kDumpWave);
         float *tabw = (float *)(smem + kTabBase + wave_e * kTabBytes);
         store_tables(fl, tabs, tabw, lane_e);
         lds_cf32 *tab = (lds_cf32 *)(lds_void *)tabw;
         const float sr = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tabw[512])));
-        f32x4 t = epilogue_half_any(p, fl, sr, dump, tab, 0, m_wave, n_wave, ldc_e, rows_ok, cols_ok, lane_e);
+        f32x4 t = epilogue_half_any<G::kCols>(p, fl, sr, dump, tab, 0, m_wave, n_wave, ldc_e, rows_ok, cols_ok, lane_e);
         if (pass == 0) STAMP256(3);
-        FP8MI_GEMM256_DUMP_HI();
-        t += epilogue_half_any(p, fl, sr, dump, tab, 1, m_wave, n_wave, ldc_e, rows_ok, cols_ok, lane_e);
+        if constexpr (BN == 128) {
+            FP8MI_GEMM256_DUMP_HI_N128();
+        } else {
+            FP8MI_GEMM256_DUMP_HI();
+        }
+        (void)acc6; (void)acc7;
+        t += epilogue_half_any<G::kCols>(p, fl, sr, dump, tab, 1, m_wave, n_wave, ldc_e, rows_ok, cols_ok, lane_e);
         if (!(flags & kFNanZero) || pass == 1) break;
         const float sum = (t[0] + t[1]) + (t[2] + t[3]);
         if (sum != sum) *flag = 1;
@@ -387,7 +409,7 @@ bool fp8mi_gemm256_supported(const MMParams &p)
 {
     const int esz = p.out_dtype == FP8MI_F32 ? 4 : 2;
     return fp8mi_gemm_supported(p) && p.M < 0x7FFFFF00 && p.N < 0x7FFFFF00 && (p.N % (16 / esz)) == 0 && (p.K % BK) == 0 && p.K >= 2 * BK && p.split <= 1 &&
-           ((p.ldc * esz) % 16) == 0 && (((uintptr_t)p.C) % 16) == 0 && ((p.M + kBM - 1) / kBM) * ((p.N + kBN - 1) / kBN) <= 0x7FFFFFFF &&
+           ((p.ldc * esz) % 16) == 0 && (((uintptr_t)p.C) % 16) == 0 && ((p.M + kBM - 1) / kBM) * ((p.N + 127) / 128) <= 0x7FFFFFFF &&
            p.ldc * esz * 128 < 0x7FFF0000;   // the epilogue addresses a wave tile (128 rows) with 32-bit offsets
 }
 
@@ -398,14 +420,18 @@ extern "C" int fp8mi_debug_read_stamps256(unsigned long long *out, int n)
 }
 #endif
 
+// variant: 0 = the product loop on 256x256 tiles, 1000 = the same schedule on 256x128 tiles; others (diagnostic build) = schedule variants
 int fp8mi_launch_gemm256(const MMParams &p, int variant, hipStream_t s)
 {
-    const int64_t tm = (p.M + kBM - 1) / kBM, tn = (p.N + kBN - 1) / kBN;
+    const int bn = variant == 1000 ? 128 : 256;
+    const int64_t tm = (p.M + kBM - 1) / kBM, tn = (p.N + bn - 1) / bn;
+    if (tm * tn > 0x7FFFFFFF) return FP8MI_E_UNSUPPORTED;
     const unsigned grid = (unsigned)(tm * tn);
     switch (variant) {
-    case 0: return fp8mi_launch(gemm256_kernel<0>, dim3(grid), dim3(kThreads256), s, p, (int)tm, (int)tn, (int)grid);
+    case 0: return fp8mi_launch(gemm256_kernel<0, 256>, dim3(grid), dim3(kThreads256), s, p, (int)tm, (int)tn, (int)grid);
+    case 1000: return fp8mi_launch(gemm256_kernel<0, 128>, dim3(grid), dim3(kThreads256), s, p, (int)tm, (int)tn, (int)grid);
 #ifdef FP8MI_DIAG
-#define X(v) case v: return fp8mi_launch(gemm256_kernel<v>, dim3(grid), dim3(kThreads256), s, p, (int)tm, (int)tn, (int)grid);
+#define X(v) case v: return fp8mi_launch(gemm256_kernel<v, 256>, dim3(grid), dim3(kThreads256), s, p, (int)tm, (int)tn, (int)grid);
     FP8MI_GEMM256_VARIANTS
 #undef X
 #endif

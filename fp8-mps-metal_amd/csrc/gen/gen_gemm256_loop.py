@@ -72,9 +72,10 @@ VARIANTS = {
 }
 P = dict(PRODUCT)
 
+TN = 8   # W fragments per wave: 8 = 256x256 workgroup tile (wave 128x128), 4 = 256x128 (wave 128x64); set by the emitters below
 WF = lambda tn: 128 + 8 * tn
 XF = lambda tm: 192 + 8 * tm
-ACC = lambda tn, tm: (tm * 8 + tn) * 4   # fragment row tm = one block of 32 AGPRs = one asm output operand
+ACC = lambda tn, tm: (tm * TN + tn) * 4   # fragment row tm = one block of 4 TN AGPRs
 
 
 def mfma(tn, tm):
@@ -102,7 +103,7 @@ def dma_block(slot_m0, kreg, first=True):
     VGPR (v118 = va0 / vb0 + jo x row-group stride) and only k in the scalar offset: the hardware range-checks the VGPR offset
     against the descriptor's num_records, so the rows of a ragged last m-tile beyond M read as zeros without a mask."""
     groups = []
-    for j in range(16):
+    for j in range(8 + TN):   # 8 row groups of the A panel, TN of the B panel per wave
         g = []
         if j == 0:
             g += [f"s_mov_b32 m0, {slot_m0}", f"s_mov_b32 %[t0], {kreg}", "v_mov_b32 v118, %[va0]"]
@@ -137,17 +138,18 @@ def swap_slots():
 
 def canonical_prologue_reads():
     out = []
-    for tn in range(7):
+    for tn in range(TN - 1):
         out += rdW(tn, "c")
     for tm in range(8):
         out += rdX(tm, "c")
-    out += rdW(7, "c")
+    out += rdW(TN - 1, "c")
     return out
 
 
 def step(dma, reads):
-    pre = [[] for _ in range(64)]
-    post = [[] for _ in range(64)]
+    NM, LR = 8 * TN, 8 * (TN - 1)   # MFMAs per step, index of the first MFMA of the last row
+    pre = [[] for _ in range(NM)]
+    post = [[] for _ in range(NM)]
     for tm in range(8):
         pre[tm].append(f"s_waitcnt lgkmcnt({min(15, 2 * (7 - tm) + 2)})")
     if reads:
@@ -156,25 +158,27 @@ def step(dma, reads):
         post[BARRIER_AFTER] += ["s_waitcnt lgkmcnt(0)" if P["no_vmwait"] else f"s_waitcnt vmcnt({vm}) lgkmcnt(0)"]
         if not P["no_barrier"]:
             post[BARRIER_AFTER] += ["s_barrier"]
-        for tn in range(7):  # W fragment tn is dead behind its row; its re-read also has to sit behind the barrier
+        for tn in range(TN - 1):  # W fragment tn is dead behind its row; its re-read also has to sit behind the barrier
             post[max(8 * tn + 7, BARRIER_AFTER)] += rdW(tn, "n")
         for tm in range(8):
-            post[min(63, 56 + tm + P["xdelay"])] += rdX(tm, "n")
-        post[63] += rdW(7, "n")
-        pre[56].append("s_waitcnt lgkmcnt(14)")
+            post[min(NM - 1, LR + tm + P["xdelay"])] += rdX(tm, "n")
+        post[NM - 1] += rdW(TN - 1, "n")
+        pre[LR].append(f"s_waitcnt lgkmcnt({2 * (TN - 1)})")
     else:
-        pre[56].append("s_waitcnt lgkmcnt(0)")
+        pre[LR].append("s_waitcnt lgkmcnt(0)")
+    every = P["dma_every"] if TN == 8 else 2   # 12 instructions under 24 MFMAs on the 256x128 tile
+    pf_at = P["pf_at"] if TN == 8 else NM - 2
     if dma and not P["no_dma"]:
         for j, g in enumerate(dma_block("%[m0_c]", "%[k2]")):
-            post[min(63, P["dma_first"] - 1 + j * P["dma_every"])] += g
+            post[min(NM - 1, P["dma_first"] - 1 + j * every)] += g
         if P["pf"] and not P["pf_stagger"]:
-            post[P["pf_at"]] += pf_group()
+            post[pf_at] += pf_group()
         elif P["pf"]:
             for w in range(4):   # one copy per wave, each behind a scalar test of the wave's index
                 g = [f"s_cmp_lg_u32 %[wave], {w}", f"s_cbranch_scc1 3{w}f"] + pf_group() + [f"3{w}:"]
-                post[P["pf_at"] - P["pf_stagger"] * (3 - w)] += g
+                post[pf_at - P["pf_stagger"] * (3 - w)] += g
     out = []
-    for i in range(64):
+    for i in range(NM):
         out += pre[i]
         if not P["no_mfma"]:
             out.append(mfma(i // 8, i % 8))
@@ -187,14 +191,14 @@ def step(dma, reads):
 
 
 def dump(rows):
-    """fragment rows `rows` (4 of them) of this wave's accumulators -> its quarter of the ring, fp32, swizzled chunks"""
+    """fragment rows `rows` (4 of them) of this wave's accumulators -> its share of the ring, fp32 rows of 16 TN columns, chunks swizzled"""
     L = []
-    for tn in range(8):
+    for tn in range(TN):
         L += [f"v_xor_b32 v{120 + tn}, {tn * 64}, %[dkey]", f"v_add_u32 v{120 + tn}, %[drow], v{120 + tn}"]
     for tm in rows:
-        for tn in range(8):
+        for tn in range(TN):
             a = ACC(tn, tm)
-            L.append(f"ds_write_b128 v{120 + tn}, a[{a}:{a + 3}] offset:{(tm % 4) * 8192}")
+            L.append(f"ds_write_b128 v{120 + tn}, a[{a}:{a + 3}] offset:{(tm % 4) * 1024 * TN}")
     L.append("s_waitcnt lgkmcnt(0)")
     return L
 
@@ -285,7 +289,7 @@ def pipelined2():
 
 
 def zero_acc():
-    return [f"v_accvgpr_write_b32 a{i}, 0" for i in range(256)]
+    return [f"v_accvgpr_write_b32 a{i}, 0" for i in range(32 * TN)]
 
 
 def pipelined():
@@ -300,7 +304,7 @@ def pipelined():
     if P["pf"]:
         L += pf_group()
     L += zero_acc()
-    L += [f"s_waitcnt vmcnt({17 if P['pf'] else 16})", "s_barrier"]
+    L += [f"s_waitcnt vmcnt({8 + TN + (1 if P['pf'] else 0)})", "s_barrier"]
     L += canonical_prologue_reads()
     L += ["s_cmp_eq_u32 %[nloop], 0", "s_cbranch_scc1 2f", "1:"]
     L += step(True, True)
@@ -327,9 +331,9 @@ def scrub_step(dma):
         for g in dma_block("%[m0_c]", "%[k2]"):
             L += g
         L.append("s_add_u32 %[k2], %[k2], 0x80")
-    for r in range(128, 256):
+    for r in list(range(128, 128 + 8 * TN)) + list(range(192, 256)):
         L += scrub_reg(r)
-    for i in range(64):
+    for i in range(8 * TN):
         L.append(mfma(i // 8, i % 8))
     L += swap_slots()
     return L
@@ -359,7 +363,8 @@ def emit(name, lines, scrub):
     print("    asm volatile( \\")
     for l in lines:
         print(f'        "{l}\\n\\t" \\')
-    outs = [f'"={{a[{32 * t}:{32 * t + 31}]}}"(acc{t})' for t in range(4, 8)]
+    nblk = TN // 2   # fragment rows 4..7 (16 TN AGPRs) as 32-float operands: acc4.. pinned to a[16 TN + 32 i : + 31]
+    outs = [f'"={{a[{16 * TN + 32 * i}:{16 * TN + 32 * i + 31}]}}"(acc{4 + i})' for i in range(nblk)]
     outs += ['[alo_c] "+v"(alo_c)', '[ahi_c] "+v"(ahi_c)', '[blo_c] "+v"(blo_c)', '[bhi_c] "+v"(bhi_c)',
             '[alo_n] "+v"(alo_n)', '[ahi_n] "+v"(ahi_n)', '[blo_n] "+v"(blo_n)', '[bhi_n] "+v"(bhi_n)',
             '[k2] "+s"(k2)', '[m0_c] "+s"(m0_c)', '[m0_n] "+s"(m0_n)', '[nloop] "+s"(nloop)', '[t0] "=&s"(t0)', '[t1] "=&s"(t1)']
@@ -367,22 +372,22 @@ def emit(name, lines, scrub):
         outs += ['[vt0] "=&v"(vt0)', '[vt1] "=&v"(vt1)']
     ins = ['[va0] "v"(va0)', '[vb0] "v"(vb0)', '[vscale] "v"(vscale)', '[ra] "s"(ra)', '[rb] "s"(rb)', '[sa] "s"(sa)', '[sb] "s"(sb)',
            '[drow] "v"(drow)', '[dkey] "v"(dkey)', '[pfoff] "v"(pfoff)', '[rpf] "s"(rpf)', '[klast] "s"(klast)', '[wave] "s"(wave_s)']
-    clob = [f'"v{i}"' for i in range(118, 256)] + [f'"a{i}"' for i in range(128)] + ['"scc"', '"memory"']
+    clob = [f'"v{i}"' for i in range(118, 256)] + [f'"a{i}"' for i in range(16 * TN)] + ['"scc"', '"memory"']
     print("        : " + ", ".join(outs) + " \\")
     print("        : " + ", ".join(ins) + " \\")
     print("        : " + ", ".join(clob) + ")")
     print()
 
 
-def emit_dump_hi():
-    print("#define FP8MI_GEMM256_DUMP_HI() \\")
+def emit_dump_hi(name):
+    print(f"#define {name}() \\")
     print("    asm volatile( \\")
     for l in dump(range(4, 8)):
         print(f'        "{l}\\n\\t" \\')
-    ins = [f'"{{a[{32 * t}:{32 * t + 31}]}}"(acc{t})' for t in range(4, 8)] + ['[drow] "v"(drow)', '[dkey] "v"(dkey)']
+    ins = [f'"{{a[{16 * TN + 32 * i}:{16 * TN + 32 * i + 31}]}}"(acc{4 + i})' for i in range(TN // 2)] + ['[drow] "v"(drow)', '[dkey] "v"(dkey)']
     print("        : \\")
     print("        : " + ", ".join(ins) + " \\")
-    print("        : " + ", ".join(f'"v{i}"' for i in range(120, 128)) + ', "memory")')
+    print("        : " + ", ".join(f'"v{i}"' for i in range(120, 120 + TN)) + ', "memory")')
     print()
 
 
@@ -391,7 +396,13 @@ if __name__ == "__main__":
     print(f"// product schedule: {PRODUCT}")
     emit("FP8MI_GEMM256_LOOP", pipelined2() if P["schedule"] == 2 else pipelined(), False)
     emit("FP8MI_GEMM256_LOOP_SCRUB", scrubbed(), True)
-    emit_dump_hi()
+    emit_dump_hi("FP8MI_GEMM256_DUMP_HI")
+    TN = 4   # the 256x128 workgroup tile (wave 128x64): same schedule, 32 MFMAs per step
+    P.clear(); P.update(PRODUCT)
+    emit("FP8MI_GEMM256_LOOP_N128", pipelined(), False)
+    emit("FP8MI_GEMM256_LOOP_SCRUB_N128", scrubbed(), True)
+    emit_dump_hi("FP8MI_GEMM256_DUMP_HI_N128")
+    TN = 8
     print("#ifdef FP8MI_DIAG  // schedule variants and timing-only ablations (libfp8mi_diag.so, kernel ids 80 + variant)")
     for v, over in sorted(VARIANTS.items()):
         P.clear(); P.update(PRODUCT); P.update(over)

@@ -40,6 +40,7 @@ KERNEL_GEMM_64x128 = 14
 KERNEL_GEMV_FP32 = 18
 KERNEL_GEMV_MX = 19
 KERNEL_GEMM_256W = 20
+KERNEL_GEMM_256x128W = 21
 WS_COUNTER_BYTES = 4096
 EPILOGUE_TRANSPOSED = 0x100  # OR into bias_dtype (include/fp8mi.h)
 

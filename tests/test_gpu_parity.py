@@ -52,7 +52,7 @@ def clean_bytes(rng, shape):
 
 
 def uses_mfma(kernel, M, K):
-    if kernel in TILE_KERNELS or kernel in (L.KERNEL_SKINNY, L.KERNEL_GEMV_MX, L.KERNEL_GEMM_256W):
+    if kernel in TILE_KERNELS or kernel in (L.KERNEL_SKINNY, L.KERNEL_GEMV_MX, L.KERNEL_GEMM_256W, L.KERNEL_GEMM_256x128W):
         return True
     if M == 1 and kernel in (L.KERNEL_AUTO, L.KERNEL_GEMV):
         return K % 16 == 0 and K > 4096   # the vec-mat hands deep K to the matrix core; K <= 4096 (config C1) stays fp32 FMA
@@ -574,7 +574,8 @@ def test_fused_epilogue(native, cuda, oracle, out_dtype, M):
 @pytest.mark.parametrize("M,K,N", [(256, 256, 256), (256, 384, 512), (512, 1024, 256), (768, 640, 1024), (256, 4096, 256),
                                    (300, 512, 256), (257, 384, 512), (129, 1024, 256), (1000, 640, 768), (1, 256, 256),
                                    (256, 384, 264), (512, 512, 1000), (300, 640, 520), (64, 1024, 8)])
-def test_gemm256w_parity_and_bits_of_the_ring_kernel(native, cuda, oracle, M, K, N):
+@pytest.mark.parametrize("wk", [L.KERNEL_GEMM_256W, L.KERNEL_GEMM_256x128W])
+def test_gemm256w_parity_and_bits_of_the_ring_kernel(native, cuda, oracle, M, K, N, wk):
     """The generated-assembly loop keeps the ring kernels' LDS image, fragment -> MFMA operand map and K order, so its
     result must equal the unsplit ring kernel's BIT FOR BIT (what makes a sharded linear equal the unsharded one does
     not depend on which tile kernel a shape lands on) and the oracle's within the matrix-core tolerance; every epilogue
@@ -589,15 +590,15 @@ def test_gemm256w_parity_and_bits_of_the_ring_kernel(native, cuda, oracle, M, K,
     tA, tB = dev(A, cuda), dev(B, cuda)
 
     def both(**kw):
-        a = native.fp8_scaled_mm(tA, tB, kernel=L.KERNEL_GEMM_256W, **kw)
+        a = native.fp8_scaled_mm(tA, tB, kernel=wk, **kw)
         b = native.fp8_scaled_mm(tA, tB, kernel=L.KERNEL_GEMM_256, split_k=1, **kw)
         assert torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(), b.nan_to_num()), kw.keys()
         return a
 
-    check_mm(oracle, native, cuda, A, B, [0.01], [0.02], kernel=L.KERNEL_GEMM_256W)
-    check_mm(oracle, native, cuda, A, B, sa, sb, kernel=L.KERNEL_GEMM_256W, bias=bias, scale_result=0.25)
-    check_mm(oracle, native, cuda, A, B, sa, [0.02], kernel=L.KERNEL_GEMM_256W, bias=bias, out_dtype=torch.bfloat16)
-    check_mm(oracle, native, cuda, A, B, [0.01], sb, kernel=L.KERNEL_GEMM_256W, out_dtype=torch.float16)
+    check_mm(oracle, native, cuda, A, B, [0.01], [0.02], kernel=wk)
+    check_mm(oracle, native, cuda, A, B, sa, sb, kernel=wk, bias=bias, scale_result=0.25)
+    check_mm(oracle, native, cuda, A, B, sa, [0.02], kernel=wk, bias=bias, out_dtype=torch.bfloat16)
+    check_mm(oracle, native, cuda, A, B, [0.01], sb, kernel=wk, out_dtype=torch.float16)
     s1, sN, sM = torch.full((1,), 0.01), dev(sb, cuda), dev(sa, cuda)
     for od in (torch.float32, torch.bfloat16, torch.float16):
         both(scale_a=s1, scale_b=s1, out_dtype=od)
@@ -612,14 +613,15 @@ def test_gemm256w_parity_and_bits_of_the_ring_kernel(native, cuda, oracle, M, K,
     A[min(3, M - 1), 17] = 0x7F
     B[N - 1, K - 1] = 0xFF
     tA, tB = dev(A, cuda), dev(B, cuda)
-    check_mm(oracle, native, cuda, A, B, sa, sb, kernel=L.KERNEL_GEMM_256W, bias=bias)
+    check_mm(oracle, native, cuda, A, B, sa, sb, kernel=wk, bias=bias)
     both(scale_a=sM, scale_b=sN, bias=dev(bias, cuda), out_dtype=torch.bfloat16)
     got = both(scale_a=s1, scale_b=s1, nan_mode=L.NAN_PROPAGATE).cpu().numpy()
     nan = np.isnan(got)
     assert nan[min(3, M - 1), :].all() and nan[:, N - 1].all() and nan.sum() == N + M - 1
 
 
-def test_gemm256w_random_shapes(native, cuda, oracle):
+@pytest.mark.parametrize("wk", [L.KERNEL_GEMM_256W, L.KERNEL_GEMM_256x128W])
+def test_gemm256w_random_shapes(native, cuda, oracle, wk):
     """Seeded random shapes inside the kernel's envelope (any M, N a multiple of 8, K a multiple of 128) with random
     epilogue forms, forced through the 256W kernel: oracle tolerance and the ring kernel's bits."""
     rng = np.random.default_rng(2026)
@@ -635,7 +637,7 @@ def test_gemm256w_random_shapes(native, cuda, oracle):
         od = [torch.float32, torch.bfloat16, torch.float16][int(rng.integers(3))]
         if rng.integers(4) == 0:
             A[int(rng.integers(M)), int(rng.integers(K))] = 0x7F   # a NaN byte: the scrubbing redo
-        got = check_mm(oracle, native, cuda, A, B, sa, sb, kernel=L.KERNEL_GEMM_256W, bias=bias, out_dtype=od)
+        got = check_mm(oracle, native, cuda, A, B, sa, sb, kernel=wk, bias=bias, out_dtype=od)
         kw = {"bias": dev(bias, cuda)} if bias is not None else {}
         ref = native.fp8_scaled_mm(dev(A, cuda), dev(B, cuda), dev(sa, cuda), dev(sb, cuda), out_dtype=od, kernel=L.KERNEL_GEMM_256,
                                    split_k=1, **kw)
@@ -659,6 +661,7 @@ def test_gemm256w_envelope_dispatch_and_exactness(native, cuda, oracle):
     A = (0x28 + rng.integers(0, 0x20, size=(512, 1024))).astype(np.uint8)
     B = (0x28 + rng.integers(0, 0x20, size=(768, 1024))).astype(np.uint8)
     check_mm(oracle, native, cuda, A, B, [0.5], [2.0], kernel=L.KERNEL_GEMM_256W, tol=MM_TOL)
+    check_mm(oracle, native, cuda, A, B, [0.5], [2.0], kernel=L.KERNEL_GEMM_256x128W, tol=MM_TOL)
     # AUTO on a large shape of whole tiles: the same bits as the explicit id and as the ring kernel
     g = torch.Generator(device=cuda).manual_seed(5)
     a = torch.randint(0, 0x7F, (2048, 1024), dtype=torch.uint8, device=cuda, generator=g)
@@ -667,7 +670,8 @@ def test_gemm256w_envelope_dispatch_and_exactness(native, cuda, oracle):
     r_auto = native.fp8_scaled_mm(a, b, s, s, out_dtype=torch.bfloat16)
     r_w = native.fp8_scaled_mm(a, b, s, s, out_dtype=torch.bfloat16, kernel=L.KERNEL_GEMM_256W)
     r_ring = native.fp8_scaled_mm(a, b, s, s, out_dtype=torch.bfloat16, kernel=L.KERNEL_GEMM_256, split_k=1)
-    assert torch.equal(r_auto, r_w) and torch.equal(r_w, r_ring)
+    r_n = native.fp8_scaled_mm(a, b, s, s, out_dtype=torch.bfloat16, kernel=L.KERNEL_GEMM_256x128W)   # (what AUTO picks for this shape: 256 tiles of 256x128)
+    assert torch.equal(r_auto, r_w) and torch.equal(r_w, r_ring) and torch.equal(r_n, r_ring)
     # padded strides
     bufA = torch.randint(0, 0x7F, (256, 640), dtype=torch.uint8, device=cuda, generator=g)
     bufB = torch.randint(0, 0x7F, (512, 768), dtype=torch.uint8, device=cuda, generator=g)
