@@ -596,10 +596,12 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
         const double us256 = rounds(t256, cus, 0.75, 0.25) * (w256 ? 8.5 + 1.35 * nk : 8.0 + 1.6 * nk);  // (a quarter-filled round of 256x256
         const double us128 = rounds(t128, 2 * cus, 0.55, 0.45) * (5.5 + 0.87 * nk);  //  tiles still costs 0.8 of a full one)
         const double us64 = rounds(t64, cus, 0.6, 0.4) * (5.0 + 0.37 * nk);
-        // ... and its 256x128 form at 1.5 + 0.89 nk per round, a partly filled round costing nearly a full one (fitted:
-        // 2048x4096x4096 29.8 us, 1024x8192x8192 58.5, 4096x3072x1536 23.3, 3072^3 45.6, FLUX 136.8; profiles/r02_large_shapes.txt)
+        // ... and its 256x128 form at max(1.5 + 0.89 nk, 4.5 + 0.75 nk) per round (deep K: the DMA stream; shallow K: the per-tile
+        // fixed cost), a partly filled round costing nearly a full one (fitted: 2048x4096x4096 29.8 us, 1024x8192x8192 58.5,
+        // 4096x3072x1536 23.3, 3072^3 45.6, FLUX 136.8, 16384x1024x8192 168.6; profiles/r02_large_shapes.txt)
         const double t256n = (double)(((p.M + 255) / 256) * ((p.N + 127) / 128));
-        const double us256n = w256 ? rounds(t256n, cus, 0.85, 0.15) * (1.5 + 0.89 * nk) : 1e30;
+        const double per256n = 1.5 + 0.89 * nk > 4.5 + 0.75 * nk ? 1.5 + 0.89 * nk : 4.5 + 0.75 * nk;
+        const double us256n = w256 ? rounds(t256n, cus, 0.85, 0.15) * per256n : 1e30;
         if (t64 <= cus / 2) {
             // few tiles: one per CU at most, split-K (launch<>) fills the rest of the chip when a workspace came along;
             // with few rows of A the tile is better spent on N
