@@ -240,3 +240,15 @@ def test_product_kernels_do_not_spill():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_spills.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_generated_gemm_loop_is_current():
+    """csrc/fp8mi_gemm256_loop.inc is generated (csrc/gen/gen_gemm256_loop.py) and committed: the committed text must be
+    what the generator produces now (an edited generator without a regenerated loop would ship a stale schedule)."""
+    import sys
+    gen = os.path.join(ROOT, "fp8-mps-metal_amd", "csrc", "gen", "gen_gemm256_loop.py")
+    inc = os.path.join(ROOT, "fp8-mps-metal_amd", "csrc", "fp8mi_gemm256_loop.inc")
+    r = subprocess.run([sys.executable, gen], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout == open(inc).read(), "regenerate: python csrc/gen/gen_gemm256_loop.py > csrc/fp8mi_gemm256_loop.inc"
+
