@@ -257,7 +257,10 @@ def test_transposed_epilogue_equals_untransposed_bits(native, cuda, oracle):
         sw = torch.from_numpy(rng.uniform(0.005, 0.02, size=N).astype(np.float32)).to(cuda)
         b = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(cuda)
         for od in (torch.float32, torch.bfloat16, torch.float16):
-            for kern in (L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256, L.KERNEL_GEMM_64x128):
+            kerns = [L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256, L.KERNEL_GEMM_64x128]
+            if K % 128 == 0 and M % 8 == 0 and N % 8 == 0:   # the one-wave-per-SIMD kernels' envelope (whole K-steps, 16-byte column groups)
+                kerns += [L.KERNEL_GEMM_256W, L.KERNEL_GEMM_256x128W]
+            for kern in kerns:
                 plain = native.fp8_scaled_mm(X, W, sx, sw, bias=b, out_dtype=od, kernel=kern, split_k=1)
                 big = torch.full((N + 3, M + 16), 7.0, dtype=od, device=cuda)      # slab with a row stride
                 slot = big[2:2 + N, :M]
