@@ -18,6 +18,7 @@ Workloads (BASELINE.json configs):
   flux     M=4096, K=3072, N=12288, bf16 out (configs[3]); with --gpus N > 1 the
            N dimension is column-sharded over the ranks and the output is
            all-gathered over RCCL/xGMI ("strong" scaling: fixed total work)
+  mid      M=2048, K=N=4096, bf16 out  (a mid-size GEMM: one round of 256x128 tiles)
   skinny   M=4, K=N=4096               (the reference's batch-4 shape, README.md:77; GB/s)
   gemv_sq  M=1, K=N=14336              (the reference's published big GEMV shape, README.md:77-82)
   quantize / quantize_rne / dequant   2^30 elements   (configs[4]; _rne = torch/OCP rounding through the hardware convert)
@@ -107,7 +108,8 @@ MAX_STREAMS = 4
 # name -> (M, K, N); "decode" = a small batch against the C2 weight shape (split-K fills the chip)
 # "gemv_sq" = the reference's one published big GEMV shape (test_fp8_metal.py:233-235, README.md:77-82: 2.38 ms on M4 Pro)
 MM_WORKLOADS = {"gemm": (512, 4096, 4096), "gemv": (1, 14336, 4096), "flux": (4096, 3072, 12288),
-                "skinny": (4, 4096, 4096), "decode": (64, 14336, 4096), "gemv_sq": (1, 14336, 14336)}
+                "skinny": (4, 4096, 4096), "decode": (64, 14336, 4096), "gemv_sq": (1, 14336, 14336),
+                "mid": (2048, 4096, 4096)}   # "mid" = one round of 256x128 tiles (the mid-size class between C3 and FLUX)
 WEIGHT_STREAMING = ("gemv", "skinny", "decode", "gemv_sq")   # quoted in GB/s of algorithmic bytes
 TARGET_STEP_S = 0.016   # a step lasts >= 16 ms: the driver's 20 steps time >= 0.3 s of sustained work per workload
 
@@ -127,8 +129,8 @@ class Workload:
             Nl = N // world
             assert N % world == 0
             self.N = Nl
-            self.out_dtype = torch.bfloat16 if name in ("flux", "decode") else torch.float32
-            esz = 2 if name in ("flux", "decode") else 4
+            self.out_dtype = torch.bfloat16 if name in ("flux", "decode", "mid") else torch.float32
+            esz = 2 if name in ("flux", "decode", "mid") else 4
             nbuf = nbuf or max(2, -(-int(1.25 * CACHE_BYTES) // (Nl * K)))
             self.A = clean_bytes((M, K), dev, torch.Generator(device=dev).manual_seed(99))  # replicated activations
             self.Bs = [clean_bytes((Nl, K), dev, gen) for _ in range(nbuf)]
@@ -152,9 +154,9 @@ class Workload:
                 self.Cs = [torch.empty(Nl, M, dtype=self.out_dtype, device=dev) for _ in range(2)]
             else:
                 self.Cs = [torch.empty(M, Nl, dtype=self.out_dtype, device=dev) for _ in range(2)]
-            self.code = L.BF16 if name in ("flux", "decode") else L.F32
+            self.code = L.BF16 if name in ("flux", "decode", "mid") else L.F32
             self.desc = {"workload": f"{name}: M={M} K={K} N={N} e4m3fn, per-tensor scales, "
-                                     f"{'bf16' if name in ('flux', 'decode') else 'fp32'} out, {nbuf} rotating weight buffers",
+                                     f"{'bf16' if name in ('flux', 'decode', 'mid') else 'fp32'} out, {nbuf} rotating weight buffers",
                          "M": M, "K": K, "N": N}
         elif name == "linear":
             # end-to-end dynamic-quant linear on the FLUX shape: bf16 activations -> amax -> scaled encode -> scaled_mm
@@ -586,7 +588,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="auto", choices=["auto", "gemm", "gemv", "gemv_sq", "flux", "skinny", "decode", "linear",
+    ap.add_argument("--workload", default="auto", choices=["auto", "gemm", "gemv", "gemv_sq", "flux", "mid", "skinny", "decode", "linear",
                                                            "quantize", "quantize_rne", "dequant"])
     ap.add_argument("--kernel", type=int, default=L.KERNEL_AUTO, help="force an FP8MI_KERNEL_* id")
     ap.add_argument("--nbuf", type=int, default=None, help="override the number of rotating weight buffers "
@@ -676,7 +678,7 @@ def main():
 
     if world == 1 and args.workload == "auto" and not args.no_secondary and not args.force_sharded:
         sec = {}
-        for name in ("gemv", "gemv_sq", "flux", "skinny", "decode", "linear", "quantize", "quantize_rne", "dequant"):
+        for name in ("gemv", "gemv_sq", "flux", "mid", "skinny", "decode", "linear", "quantize", "quantize_rne", "dequant"):
             try:
                 r = measure(name, dev, max(3, args.steps // 2), max(1, args.warmup // 2), 1, 0, L.KERNEL_AUTO,
                             with_cpu=(name == "gemv" and not args.no_cpu_baseline), info=info, ceilings=ceilings)
