@@ -72,6 +72,36 @@ int fp8mi_cu_count()
     return n;
 }
 
+// The kernel the automatic dispatch runs for a problem (host-only arithmetic on shapes, strides, alignment and the CU count;
+// exported as fp8mi_choose_kernel and tested on the CPU).  Rules and the measurements behind them:
+static int choose_kernel(const MMParams &p)
+{
+    if (fp8mi_gemv_supported(p)) return FP8MI_KERNEL_GEMV;
+    if (fp8mi_gemv_mx_supported(p)) {
+        // 2..8 rows of x on the vec-mat's weight-streaming structure (tools/check_gemv_mx.py time, MI355X): ahead of
+        // the skinny and the split-K tile kernel for M <= 4 everywhere measured (K = N = 4096: 5.6 / 6.3 vs 7.8 us;
+        // K = 14336, N = 4096: 12.2 vs 16-17 us) and for 5 <= M <= 8 once K > 4096 on matrices the tile kernel
+        // cannot fill the chip with (K = 14336, N = 4096: 14.3 vs 17.4 us; K = N = 8192: 15.1 vs 17.9 us)
+        const int64_t t64 = (p.N + 63) / 64, cus = fp8mi_cu_count();
+        if (p.M <= 4 || (p.K > 4096 && t64 < (3 * cus) / 4)) return FP8MI_KERNEL_GEMV_MX;
+    }
+    if (p.M >= 2 && p.M <= 48 && fp8mi_skinny_supported(p)) {
+        // measured (tools/sweep_small_m.py): on small weight matrices the weight-streaming skinny kernel wins up
+        // to M = 48 (K = N = 4096: 8.5-11.4 vs 11.4-12.6 us); on large ones (N*K >= 24 MiB) the split-K tile
+        // kernel wins from M = 2 (K = 4096, N = 14336: 13.7 vs 25.4 us; M = 32, K = 14336, N = 4096: 17.7 vs
+        // 28.4 us) - it needs the workspace
+        const bool big = (double)p.N * (double)p.K >= 24.0 * 1048576.0;
+        // ... and when N alone yields >= 192 tiles of 128x64 the tile kernel needs no split to fill the chip
+        // (K = 4096, N = 14336: 14-15 us for every M <= 64, skinny 20-36 us: x is re-read by every 16-row workgroup)
+        // (from 128 tiles on while K <= 4096: K = 4096, N = 8192: 14-15 vs 16-19 us; at K = 8192 the 128 busy CUs lose)
+        const int64_t t64 = (p.N + 63) / 64, cus = fp8mi_cu_count();
+        const bool wide = t64 >= (3 * cus) / 4 || (t64 >= cus / 2 && p.K <= 4096);
+        if (!(fp8mi_gemm_supported(p) && ((p.ws && p.split != 1 && big) || wide))) return FP8MI_KERNEL_SKINNY;
+    }
+    if (p.K > 0 && fp8mi_gemm_supported(p)) return fp8mi_choose_gemm_variant(p);
+    return FP8MI_KERNEL_GENERIC;
+}
+
 extern "C" {
 
 int fp8mi_profile_begin(int max_launches)
@@ -195,33 +225,8 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     p.ws_bytes = workspace ? workspace_bytes : 0;
     hipStream_t s = (hipStream_t)stream;
 
+    if (kernel == FP8MI_KERNEL_AUTO) kernel = choose_kernel(p);   // (every id it returns passes its own envelope check below)
     switch (kernel) {
-    case FP8MI_KERNEL_AUTO:
-        if (fp8mi_gemv_supported(p)) return hip_result(fp8mi_launch_gemv(p, false, s), "gemv");
-        if (fp8mi_gemv_mx_supported(p)) {
-            // 2..8 rows of x on the vec-mat's weight-streaming structure (tools/check_gemv_mx.py time, MI355X): ahead of
-            // the skinny and the split-K tile kernel for M <= 4 everywhere measured (K = N = 4096: 5.6 / 6.3 vs 7.8 us;
-            // K = 14336, N = 4096: 12.2 vs 16-17 us) and for 5 <= M <= 8 once K > 4096 on matrices the tile kernel
-            // cannot fill the chip with (K = 14336, N = 4096: 14.3 vs 17.4 us; K = N = 8192: 15.1 vs 17.9 us)
-            const int64_t t64 = (p.N + 63) / 64, cus = fp8mi_cu_count();
-            if (p.M <= 4 || (p.K > 4096 && t64 < (3 * cus) / 4)) return hip_result(fp8mi_launch_gemv_mx(p, s), "gemv-mx");
-        }
-        if (p.M >= 2 && p.M <= 48 && fp8mi_skinny_supported(p)) {
-            // measured (tools/sweep_small_m.py): on small weight matrices the weight-streaming skinny kernel wins up
-            // to M = 48 (K = N = 4096: 8.5-11.4 vs 11.4-12.6 us); on large ones (N*K >= 24 MiB) the split-K tile
-            // kernel wins from M = 2 (K = 4096, N = 14336: 13.7 vs 25.4 us; M = 32, K = 14336, N = 4096: 17.7 vs
-            // 28.4 us) - it needs the workspace
-            const bool big = (double)p.N * (double)p.K >= 24.0 * 1048576.0;
-            // ... and when N alone yields >= 192 tiles of 128x64 the tile kernel needs no split to fill the chip
-            // (K = 4096, N = 14336: 14-15 us for every M <= 64, skinny 20-36 us: x is re-read by every 16-row workgroup)
-            // (from 128 tiles on while K <= 4096: K = 4096, N = 8192: 14-15 vs 16-19 us; at K = 8192 the 128 busy CUs lose)
-            const int64_t t64 = (p.N + 63) / 64, cus = fp8mi_cu_count();
-            const bool wide = t64 >= (3 * cus) / 4 || (t64 >= cus / 2 && p.K <= 4096);
-            if (!(fp8mi_gemm_supported(p) && ((p.ws && p.split != 1 && big) || wide)))
-                return hip_result(fp8mi_launch_skinny(p, s), "skinny");
-        }
-        if (K > 0 && fp8mi_gemm_supported(p)) return hip_result(fp8mi_launch_gemm(p, FP8MI_KERNEL_AUTO, s), "gemm");
-        return hip_result(fp8mi_launch_generic(p, s), "generic");
     case FP8MI_KERNEL_GEMV:
         if (!fp8mi_gemv_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "gemv kernel needs M == 1, K %% 16 == 0, 16-byte aligned rows");
         return hip_result(fp8mi_launch_gemv(p, false, s), "gemv");
@@ -263,6 +268,21 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
 #endif
         return fail(FP8MI_E_ENUM, "fp8mi_scaled_mm_ex: unknown kernel id %d", kernel);
     }
+}
+
+int fp8mi_choose_kernel(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int out_dtype, int has_workspace,
+                        int split_k)
+{
+    if (M < 0 || N < 0 || K < 0 || !dtype_ok(out_dtype) || split_k < 0) return FP8MI_E_ENUM;
+    MMParams p = {};
+    p.A = (const uint8_t *)(uintptr_t)0x10000; p.B = (const uint8_t *)(uintptr_t)0x20000; p.C = (void *)(uintptr_t)0x30000;   // aligned, never dereferenced
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.out_dtype = out_dtype;
+    p.nan_zero = 1;
+    p.split = has_workspace ? split_k : 1;
+    p.ws = has_workspace ? (uint8_t *)(uintptr_t)0x40000 : nullptr;
+    p.ws_bytes = has_workspace ? (int64_t)1 << 30 : 0;
+    return choose_kernel(p);
 }
 
 int fp8mi_scaled_mm(const uint8_t *A, const uint8_t *B_nk, void *C, const float *scale_a, const float *scale_b,

@@ -156,6 +156,7 @@ int fp8mi_launch_gemv_mx(const MMParams &p, hipStream_t s);   // 2 <= M <= 8, th
 bool fp8mi_gemv_mx_supported(const MMParams &p);
 int fp8mi_launch_gemv_mx_variant(const MMParams &p, int id, hipStream_t s);  // diagnostic library only
 int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s);
+int fp8mi_choose_gemm_variant(const MMParams &p);   // the tile kernel AUTO picks (host-only)
 bool fp8mi_gemm_supported(const MMParams &p);
 int fp8mi_launch_gemm256(const MMParams &p, int variant, hipStream_t s);   // fp8mi_gemm256.hip: whole 256x256 tiles, hand-scheduled loop
 bool fp8mi_gemm256_supported(const MMParams &p);

@@ -571,9 +571,11 @@ bool fp8mi_gemm_supported(const MMParams &p)
            (((uintptr_t)p.A) & 15u) == 0 && (((uintptr_t)p.B) & 15u) == 0 && p.lda < (1 << 22) && p.ldb < (1 << 22);
 }
 
-int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
+// The tile kernel the automatic dispatch uses for a shape the tile kernels support (host-only: fp8mi_choose_kernel, tested on the CPU)
+int fp8mi_choose_gemm_variant(const MMParams &p)
 {
-    if (variant == FP8MI_KERNEL_AUTO) {
+    int variant = FP8MI_KERNEL_GEMM_128x64;
+    {
         // Pick the tile by a small cost model fitted to per-dispatch timings on MI355X (tools/sweep_dispatch.py,
         // DESIGN.md 6): time = rounds x (fixed + per-K-step) in us, where a round is one workgroup per CU
         // (two for the 128x128 tile) and a partly filled last round costs a + b x its fill (fitted per tile).
@@ -611,6 +613,12 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
         else if (us128 <= us64) variant = FP8MI_KERNEL_GEMM_128;
         else variant = FP8MI_KERNEL_GEMM_128x64;
     }
+    return variant;
+}
+
+int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
+{
+    if (variant == FP8MI_KERNEL_AUTO) variant = fp8mi_choose_gemm_variant(p);
     switch (variant) {
     // product kernels: 8 waves, waves 0-3 (one per SIMD) issue the stage DMA (template: BM, BN, WM, WN, ring stages, loop order,
     // -, K-steps per stage, loading waves).  Loop orders (run_tile / run_tile_staggered): the small tiles issue their fragment reads

@@ -66,6 +66,7 @@ SIGNATURES = {
                                   _int, _int, _int, _int, _int, _int, _int, _vp, _i64, _vp]),
     "fp8mi_scaled_mm_workspace_bytes": (_i64, []),
     "fp8mi_workspace_reset": (_int, [_vp, _i64, _vp]),
+    "fp8mi_choose_kernel": (_int, [_i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _int]),
     "fp8mi_dequant": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
     "fp8mi_encode": (_int, [_vp, _int, _vp, _vp, _i64, _int, _vp]),
     "fp8mi_amax": (_int, [_vp, _int, _vp, _i64, _vp]),

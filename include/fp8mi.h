@@ -256,6 +256,12 @@ int fp8mi_profile_end(float *ms_out, int cap);
 int fp8mi_version(void);
 const char *fp8mi_last_error(void);
 
+/* Which kernel FP8MI_KERNEL_AUTO runs for a problem of this shape (host-only; pointers are assumed 16-byte aligned):
+ * returns an FP8MI_KERNEL_* id, or a negative error for an invalid argument.  For tests and for callers that want to log
+ * the dispatch; no counterpart in the reference (its choice is `M == 1` in fp8_mps_native.py:193-210). */
+int fp8mi_choose_kernel(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int out_dtype,
+                        int has_workspace, int split_k);
+
 #ifdef __cplusplus
 }
 #endif

@@ -252,3 +252,36 @@ def test_generated_gemm_loop_is_current():
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout == open(inc).read(), "regenerate: python csrc/gen/gen_gemm256_loop.py > csrc/fp8mi_gemm256_loop.inc"
 
+
+def test_automatic_dispatch_table():
+    """fp8mi_choose_kernel (host-only: shapes, strides, alignment, CU count - 256 when no device is visible, as on the
+    MI355X): the kernel FP8MI_KERNEL_AUTO runs for the shapes the design documents.  M = 1 is the reference's own rule
+    (fp8_mps_native.py:193-210); the rest are this library's measured choices."""
+    import sys
+    from conftest import PKG
+    sys.path.insert(0, PKG)
+    import fp8_mi355x_lib as L
+    lib = L.load()
+
+    def pick(M, K, N, out=L.BF16, ws=1, split=0, lda=None, ldb=None):
+        return lib.fp8mi_choose_kernel(M, N, K, lda or K, ldb or K, N, out, ws, split)
+
+    assert pick(1, 4096, 4096) == L.KERNEL_GEMV and pick(1, 14336, 4096) == L.KERNEL_GEMV          # configs C1, C2
+    assert pick(4, 4096, 4096) == L.KERNEL_GEMV_MX and pick(2, 4096, 14336) == L.KERNEL_GEMV_MX    # the reference's batch-4 shape
+    assert pick(8, 14336, 4096) == L.KERNEL_GEMV_MX and pick(8, 4096, 4096) == L.KERNEL_SKINNY     # 5..8 rows: deep K only
+    assert pick(6, 4096, 14336) == L.KERNEL_GEMM_128x64                                            # wide N fills the chip unsplit
+    assert pick(32, 4096, 4096) == L.KERNEL_SKINNY
+    assert pick(64, 14336, 4096) == L.KERNEL_GEMM_64x128 and pick(64, 14336, 4096, ws=0) == L.KERNEL_GEMM_128x64   # split-K needs the workspace
+    assert pick(512, 4096, 4096, out=L.F32) == L.KERNEL_GEMM_128x64                                # config C3
+    assert pick(4096, 3072, 12288) == L.KERNEL_GEMM_256W and pick(8192, 8192, 8192) == L.KERNEL_GEMM_256W   # FLUX, 8192^3
+    assert pick(4173, 3072, 12296) == L.KERNEL_GEMM_256W                                           # ragged M and N stay on it
+    assert pick(2048, 4096, 4096) == L.KERNEL_GEMM_256x128W and pick(4096, 3072, 1536) == L.KERNEL_GEMM_256x128W   # < 1 round of 256x256
+    assert pick(1536, 3072, 4096) == L.KERNEL_GEMM_256x128W                                        # the 8-GPU shard, transposed
+    assert pick(1024, 4096, 4096) == L.KERNEL_GEMM_128
+    assert pick(16384, 1024, 8192) == L.KERNEL_GEMM_256W                                           # shallow K: per-tile fixed cost decides
+    assert pick(4096, 3088, 12288) == L.KERNEL_GEMM_256                                            # K tail: ring kernel
+    assert pick(4096, 3072, 12292) in (L.KERNEL_GEMM_256, L.KERNEL_GEMM_128)                       # N not a multiple of 8 half columns: a ring kernel
+    assert pick(5, 100, 7) == L.KERNEL_GENERIC                                                     # K % 16 != 0
+    assert pick(512, 4096, 4096, lda=4100) == L.KERNEL_GENERIC                                     # rows not 16-byte aligned
+    assert lib.fp8mi_choose_kernel(-1, 1, 1, 1, 1, 1, 0, 0, 0) < 0
+
