@@ -216,6 +216,9 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     p.out_dtype = out_dtype; p.bias_dtype = bias_dtype; p.transposed = transposed;
     p.nan_zero = nan_mode == FP8MI_NAN_ZERO;
     p.debug = 0;
+#ifdef FP8MI_DIAG
+    if (const char *e = getenv("FP8MI_DEBUG")) p.debug = atoi(e);   // diagnostic library only: timing-only ablation bits
+#endif
     if (split_k < 0) return fail(FP8MI_E_ENUM, "fp8mi_scaled_mm_ws: split_k must be >= 0");
     if (workspace && ((((uintptr_t)workspace) & 15u) != 0 || workspace_bytes < FP8MI_WS_COUNTER_BYTES)) {
         workspace = nullptr;  // unusable: behave as if none was given
@@ -262,7 +265,7 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
 #ifdef FP8MI_DIAG  // diagnostic library only: schedule variants of the ring kernel (7..13, 30..37), the producer / consumer kernel
                    // (15..24) and its timing-only ablations (201..207)
         if (K > 0 && fp8mi_gemm_supported(p)) {
-            if ((kernel >= 7 && kernel <= 13) || (kernel >= 30 && kernel <= 39) || (kernel >= 120 && kernel <= 129)) return hip_result(fp8mi_launch_gemm(p, kernel, s), "gemm-variant");
+            if ((kernel >= 7 && kernel <= 13) || (kernel >= 30 && kernel <= 39) || (kernel >= 120 && kernel <= 149)) return hip_result(fp8mi_launch_gemm(p, kernel, s), "gemm-variant");
             if ((kernel >= 15 && kernel <= 29) || (kernel >= 200 && kernel < 220)) return hip_result(fp8mi_launch_gemm_pc(p, kernel, s), "gemm-pc");
         }
 #endif
@@ -301,6 +304,11 @@ int fp8mi_dequant(const uint8_t *in, void *out, const float *scale, int64_t coun
     if (!in || !out) return fail(FP8MI_E_NULL, "fp8mi_dequant: in / out must not be NULL");
     if (!dtype_ok(out_dtype)) return fail(FP8MI_E_ENUM, "fp8mi_dequant: unknown out_dtype %d", out_dtype);
     return hip_result(fp8mi_launch_dequant(in, out, scale, count, out_dtype, (hipStream_t)stream), "dequant");
+}
+
+int fp8mi_dequant_f16(const uint8_t *in, void *out, const float *scale_or_null, int64_t count, int out_dtype, void *stream)
+{
+    return fp8mi_dequant(in, out, scale_or_null, count, out_dtype, stream);   // SURVEY.md 8(b)'s name for the same entry point
 }
 
 int fp8mi_encode(const void *in, int in_dtype, uint8_t *out, const float *prescale, int64_t count, int encode_mode,

@@ -59,7 +59,8 @@ namespace {
 template <int BM, int BN, int WM, int WN, int NSTAGE_, int MODE_ = 0, int ABL_ = 0, int KS_ = 1, int LD_ = 0>
 struct Cfg {
     static constexpr int KS = KS_;      // K-steps (of 128 bytes) per ring stage: KS = 2 halves the barriers per byte
-    static constexpr int PFD = ABL_;    // L2 prefetch distance in ring stages beyond the stage being staged (0 = none): see prefetch_stage
+    static constexpr int PFD = ABL_ & 7;  // L2 prefetch distance in ring stages beyond the stage being staged (0 = none): see prefetch_stage
+    static constexpr int PFA = (ABL_ >> 3) & 1;  // diagnostic variants: one more wave warms this tile's share of its A panel's lines too
     static constexpr int MODE = MODE_;  // 0: stage DMA issued first, then fragment reads + MFMAs; 1: fragment reads first (see run_tile)
     static constexpr int NSTAGE = NSTAGE_;
     static constexpr int PF = NSTAGE_ - 1;  // K-steps of loads in flight
@@ -264,7 +265,7 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
     auto next_ks = [&]() { const int r = ks; ks = (ks + 1 == nk) ? 0 : ks + 1; return ks0 + r; };
     uint32_t sink = 0;  // C::PFD: landing register of the L2 prefetch loads (never read)
     auto prefetch = [&](int stage) {  // stage relative to ks0, clamped to this workgroup's last one
-        if (C::PFD > 0 && wave < pl.pf_waves) prefetch_stage(sink, pl.pf_off, pl.pf_rsrc, (uint32_t)((ks0 + min(stage, nk - 1)) * (BK * C::KS)));
+        if (C::PFD > 0 && wave < pl.pf_waves + C::PFA) prefetch_stage(sink, pl.pf_off, pl.pf_rsrc, (uint32_t)((ks0 + min(stage, nk - 1)) * (BK * C::KS)));
     };
 
     // prologue: PF stages in flight (stage s -> ring slot s)
@@ -479,6 +480,18 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThr
             pl.pf_rsrc = u32x4{(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pb),
                                (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(pb >> 32) & 0xFFFFu)),
                                (uint32_t)__builtin_amdgcn_readfirstlane((int)min(bytes_b, (int64_t)0x7FFFFFFF)), 0x00020000u};
+            if (C::PFA && wave == pl.pf_waves) {
+                // the wave behind the B-prefetching ones takes this tile's eighth of its A panel's lines (the 8 n-tiles an XCD runs
+                // at one time share the panel; A comes from the Infinity Cache for all but the first XCD to touch it)
+                constexpr int kLinesA = BM * C::KS / 8;
+                static_assert(!C::PFA || kLinesA <= 64, "one prefetch instruction per stage");
+                const int lia = (tile_n & 7) * kLinesA + lane, arow = lia / C::KS, ak = lia % C::KS;
+                pl.pf_off = (lane < kLinesA && arow < (int)rows_a && (p.K % (BK * C::KS)) == 0) ? (uint32_t)(arow * p.lda + ak * BK) : kOOB;
+                const uint64_t pa = (uint64_t)(p.A + m0 * p.lda);
+                pl.pf_rsrc = u32x4{(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pa),
+                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(pa >> 32) & 0xFFFFu)),
+                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)min(bytes_a, (int64_t)0x7FFFFFFF)), 0x00020000u};
+            }
         }
     }
 
@@ -513,6 +526,13 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThr
 
     // ---- split-K: partial tiles meet in the workspace; only the last-arriving slice runs the epilogue ----
     if (nsplit > 1) {
+#ifdef FP8MI_DIAG
+        // timing-only bound for a PAIRED exchange: two slices, no exchange at all - each workgroup stores the half of
+        // the tile whose rows its slice would own (wrong results: the partner's partial is never added)
+        if (p.debug & 1) {
+            if ((wave % C::kWavesM) * 2 / C::kWavesM != (kslice & 1)) return;
+        } else
+#endif
         if (!splitk_combine<C>(p, acc, smem, wg, kslice, nsplit, n_tiles)) return;
     }
 
@@ -644,6 +664,15 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     case 120: return launch<128, 128, 64, 32, 2, 0, 1, 1, 4>(p, s);            // 128x128 + L2 prefetch one stage further
     case 121: return launch<128, 128, 64, 32, 2, 0, 2, 1, 4>(p, s);            //   ... two stages
     case 122: return launch<128, 128, 64, 32, 2, 0, 4, 1, 4>(p, s);            //   ... four stages
+    case 130: return launch<128, 128, 64, 32, 2, 0, 0, 1, 4>(p, s);            // 128x128 ring depths for the paired-split bound (with SPLIT=2, FP8MI_DEBUG=1): 2 x 32 KiB (the shipped 128x128)
+    case 131: return launch<128, 128, 64, 32, 4, 1, 0, 1, 4>(p, s);            //   4 x 32 KiB
+    case 132: return launch<128, 128, 64, 32, 2, 1, 0, 2, 4>(p, s);            //   2 x 64 KiB (two K-steps per stage)
+    case 133: return launch<128, 128, 64, 32, 3, 1, 0, 1, 4>(p, s);            //   3 x 32 KiB
+    case 134: return launch<128, 128, 64, 32, 4, 1, 1, 1, 4>(p, s);            //   4 x 32 KiB + L2 prefetch
+    case 135: return launch<128, 128, 64, 32, 3, 1, 1, 1, 4>(p, s);            //   3 x 32 KiB + L2 prefetch
+    case 136: return launch<128, 128, 64, 32, 4, 0, 0, 1, 4>(p, s);            //   4 x 32 KiB, stage DMA first
+    case 140: return launch<128, 64, 32, 32, 3, 1, 9, 2, 4>(p, s);             // 128x64 as shipped + A-panel prefetch by one more wave
+    case 141: return launch<128, 64, 32, 32, 3, 1, 10, 2, 4>(p, s);            //   ... both two stages ahead
     case 7: return launch<128, 64, 64, 32, 6>(p, s);                           // 128x64, 4 waves
     case 8: return launch<128, 128, 64, 64, 4>(p, s);                          // 128x128, 4 waves, 4-stage ring
     case 9: return launch<256, 128, 64, 64, 3, 0, 0, 1, 4>(p, s);              // 256x128, 8 waves (0-3 load), 3 x 48 KiB

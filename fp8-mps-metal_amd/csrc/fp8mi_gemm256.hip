@@ -19,6 +19,10 @@
 #include "fp8mi_gemm_epi.h"
 #include "fp8mi_gemm256_loop.inc"
 
+// The generated statements list m0 (written by their LDS-DMA groups) as a clobber so that LLVM sees a definition of M0 there and never
+// carries an M0 value of its own across them; clang remarks that m0 is a reserved register (it will not be saved / restored - none is needed)
+#pragma clang diagnostic ignored "-Winline-asm"
+
 namespace {
 
 constexpr int kBM = 256, kThreads256 = 256;   // 4 waves, one per SIMD
@@ -301,46 +305,86 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
     lds_vint *flag = (lds_vint *)(lds_void *)(smem + kRing256);
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
-        // (everything below derives from a lane id produced INSIDE the loop by an opaque statement: visible as loop
-        //  invariants, hipcc hoists the ~20 registers of asm operands and epilogue addresses out of the loop and keeps
-        //  them in scratch across the epilogue)
-        int lane_l;
-        int fl_l = flags;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_l), "+s"(fl_l));
-        const int wave = FP8MI_SIMD_ID();
-        const int wm0 = (wave & 1) * 128, wn0 = (wave >> 1) * G::kCols;
-        const TabRegs tabs = load_tables(p, fl_l, m0 + wm0, n0 + wn0, G::kCols, lane_l);   // in flight under the K loop, stored to the LDS behind it
-        // staging plan (fp8mi_gemm.hip): wave w stages the 1-KiB groups w, w + 4, ... of both operands; lane -> (row, swizzled chunk)
-        const int row0 = wave * 8 + (lane_l >> 3);
-        const int chunk = (lane_l & 7) ^ (((wave & 1) * 4 + (lane_l >> 4)) & 7);
-        const uint32_t va0 = (uint32_t)(row0 * p.lda + chunk * 16), vb0 = (uint32_t)(row0 * p.ldb + chunk * 16);
-        // fragment read addresses: row r = lane & 15, lane group g reads chunks g and 4 + g of its row, swizzled by (r >> 1)
-        const int fr = lane_l & 15, fg = lane_l >> 4;
-        const uint32_t off1 = (uint32_t)(fr * BK + ((fg ^ (fr >> 1)) << 4)), off2 = (uint32_t)(fr * BK + (((4 + fg) ^ (fr >> 1)) << 4));
-        uint32_t alo_c = lds0 + wm0 * BK + off1, ahi_c = lds0 + wm0 * BK + off2;
-        uint32_t blo_c = lds0 + kBM * BK + wn0 * BK + off1, bhi_c = lds0 + kBM * BK + wn0 * BK + off2;
-        uint32_t alo_n = alo_c + kSlotBytes, ahi_n = ahi_c + kSlotBytes, blo_n = blo_c + kSlotBytes, bhi_n = bhi_c + kSlotBytes;
-        uint32_t m0_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + wave * 1024)), m0_n = m0_c + kSlotBytes;
-        uint32_t k2 = 0, nloop = (uint32_t)(nk - 2), t0, t1;
-        // L2 prefetch (gen_gemm256_loop.py pf_group): the 32 tiles an XCD runs at one time are 4 m-tiles x 8 n-tiles of one group
-        // (tile_of_block), so an A panel has 8 readers and a B panel 4; each warms its share of the lines of a later stage:
-        // wave 0 rows 64 (tile_m & 3) .. + 63 of its B panel, wave 1 rows 32 (tile_n & 7) .. + 31 of its A panel (other lanes
-        // point outside the buffer: no access).  Speed only: whoever else reads the panel finds the lines in the L2.
-        // (diagnostic variants 19-21: every wave takes a quarter of both shares - lanes 0-15 B lines, 16-23 A lines - so that the
-        //  96 lines that may miss to HBM enter the L1's miss queue in four smaller groups)
-        constexpr bool kSplitPf = V >= 19 && V <= 21;
-        uint32_t pfoff;
-        if (!kSplitPf) {
-            pfoff = (wave == 0 && lane_l < BN / 4) ? (uint32_t)((BN / 4 * (tile_m & 3) + lane_l) * p.ldb)   // (rows beyond a ragged tile's end: out of the descriptor's range, no access)
-                              : (wave == 1 && lane_l < 32) ? (uint32_t)((32 * (tile_n & 7) + lane_l) * p.lda) : kOOB;
-        } else {
-            pfoff = lane_l < 16 ? (uint32_t)((64 * (tile_m & 3) + 16 * wave + lane_l) * p.ldb) : kOOB;
-        }
-        const uint32_t wave_s = (uint32_t)wave;
-        const u32x4 rpf = (kSplitPf || wave == 0) ? rb : ra;   // (the split variants prefetch B lines only: the A panel is re-read 48x and stays in the L2)
-        const uint32_t klast = (uint32_t)((nk - 1) * BK);
-        // accumulator dump (gen_gemm256_loop.py): row fr of each fragment row, 16-byte chunk (4 tn + fg) ^ fr
+        // Operands of the generated K loops, derived from a lane id that an opaque statement produces RIGHT HERE: visible as values
+        // shared between the branches below (or as loop invariants), hipcc hoists the ~20 registers of asm operands above the branch,
+        // keeps a private copy per statement of every read-write one and spills them around the K loop (7-12 VGPRs with three
+        // statements sharing one set; tools/check_spills.py).  Every branch that runs a generated loop expands its own copy.
+        //   staging plan (fp8mi_gemm.hip): wave w stages the 1-KiB groups w, w + 4, ... of both operands; lane -> (row, swizzled chunk)
+        //   fragment reads: row r = lane & 15, lane group g reads chunks g and 4 + g of its row, swizzled by (r >> 1)
+        //   L2 prefetch (gen_gemm256_loop.py pf_group): the 32 tiles an XCD runs at one time are 4 m-tiles x 8 n-tiles of one group
+        //   (tile_of_block), so an A panel has 8 readers and a B panel 4; each warms its share of the lines of a later stage: wave 0
+        //   rows 64 (tile_m & 3) .. + 63 of its B panel, wave 1 rows 32 (tile_n & 7) .. + 31 of its A panel (other lanes point outside
+        //   the buffer: no access; diagnostic variants 19-21 split both shares over the four waves)
+        //   accumulator dump: row fr of each fragment row, 16-byte chunk (4 tn + fg) ^ fr
+#define FP8MI_G256_SETUP() \
+        int lane_l; \
+        int fl_l = flags; \
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_l), "+s"(fl_l)); \
+        const int wave = FP8MI_SIMD_ID(); \
+        const int wm0 = (wave & 1) * 128, wn0 = (wave >> 1) * G::kCols; \
+        const int row0 = wave * 8 + (lane_l >> 3); \
+        const int chunk = (lane_l & 7) ^ (((wave & 1) * 4 + (lane_l >> 4)) & 7); \
+        const uint32_t va0 = (uint32_t)(row0 * p.lda + chunk * 16), vb0 = (uint32_t)(row0 * p.ldb + chunk * 16); \
+        const int fr = lane_l & 15, fg = lane_l >> 4; \
+        const uint32_t off1 = (uint32_t)(fr * BK + ((fg ^ (fr >> 1)) << 4)), off2 = (uint32_t)(fr * BK + (((4 + fg) ^ (fr >> 1)) << 4)); \
+        uint32_t alo_c = lds0 + wm0 * BK + off1, ahi_c = lds0 + wm0 * BK + off2; \
+        uint32_t blo_c = lds0 + kBM * BK + wn0 * BK + off1, bhi_c = lds0 + kBM * BK + wn0 * BK + off2; \
+        uint32_t alo_n = alo_c + kSlotBytes, ahi_n = ahi_c + kSlotBytes, blo_n = blo_c + kSlotBytes, bhi_n = bhi_c + kSlotBytes; \
+        uint32_t m0_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + wave * 1024)), m0_n = m0_c + kSlotBytes; \
+        uint32_t k2 = 0, nloop = (uint32_t)(nk - 2), t0, t1; \
+        constexpr bool kSplitPf = V >= 19 && V <= 21; \
+        uint32_t pfoff; \
+        if (!kSplitPf) { \
+            pfoff = (wave == 0 && lane_l < BN / 4) ? (uint32_t)((BN / 4 * (tile_m & 3) + lane_l) * p.ldb) \
+                              : (wave == 1 && lane_l < 32) ? (uint32_t)((32 * (tile_n & 7) + lane_l) * p.lda) : kOOB; \
+        } else { \
+            pfoff = lane_l < 16 ? (uint32_t)((64 * (tile_m & 3) + 16 * wave + lane_l) * p.ldb) : kOOB; \
+        } \
+        const uint32_t wave_s = (uint32_t)wave; \
+        const u32x4 rpf = (kSplitPf || wave == 0) ? rb : ra; \
+        const uint32_t klast = (uint32_t)((nk - 1) * BK); \
         const uint32_t drow = lds0 + wave * kDumpWave + fr * (G::kCols * 4), dkey = (uint32_t)((fg ^ fr) << 4);
+        f32x4 t;
+        int fl_o = flags;
+        asm volatile("" : "+s"(fl_o));
+        (void)fl_o;
+        // Fused tail (diagnostic library only, FP8MI_DEBUG bit 2; gen_gemm256_loop.py fused_last_step): the epilogue of the common case -
+        // per-tensor scales, no bias / scale_result, tile whole in N - runs under the last K-step's MFMAs straight from the AGPRs.  Built,
+        // bit-identical, and SLOWER than the LDS dump (FLUX 120.7 vs 118.5 us): see the generator's note and profiles/r03_tail_probe.txt.
+#ifdef FP8MI_DIAG
+        const bool fused = (p.debug & 4) && V == 0 && pass == 0 && !(fl_o & (kFBias | kFSaRow | kFSbRow | kFSr)) && (n0 + kBN <= p.N);
+        if (fused) {
+            FP8MI_G256_SETUP();
+            const int fl_u = __builtin_amdgcn_readfirstlane(fl_l);   // (hipcc treats the results of a two-output asm statement as divergent: the scalar operands below need SGPRs)
+            const int od = (fl_u >> kFOutShift) & 3, esz = od == FP8MI_F32 ? 4 : 2;
+            const int64_t m_wave = m0 + wm0, n_wave = n0 + wn0;
+            const int rows_ok = min(max((int)p.M - (int)m_wave, 0), 128);   // rows of a ragged last m-tile beyond M: out of the descriptor's range, dropped
+            const uint64_t pc = (uint64_t)((uint8_t *)p.C + (m_wave * p.ldc + n_wave) * esz);
+            const uint32_t ldc_b = (uint32_t)(p.ldc * esz);
+            u32x4 frc = {(uint32_t)pc, (uint32_t)(pc >> 32) & 0xFFFFu, (uint32_t)rows_ok * ldc_b, 0x00020000u};
+            frc[0] = __builtin_amdgcn_readfirstlane(frc[0]); frc[1] = __builtin_amdgcn_readfirstlane(frc[1]);
+            frc[2] = __builtin_amdgcn_readfirstlane(frc[2]);
+            // lane (fr, fg) ends up with the 8 consecutive columns (fg & 1) * 16 + (fg >> 1) * 8 ..+7 of a fragment pair, row fr of row block tm
+            const uint32_t fvoff = (uint32_t)fr * ldc_b + (uint32_t)(((fg & 1) * 16 + (fg >> 1) * 8) * esz);
+            const uint32_t fsrow = 16u * ldc_b;
+            // (acc * s1) * s2: scale_a first, scale_b first in the transposed epilogue - the ring kernels' order (fp8mi_gemm_epi.h)
+            const float *fpm1 = (fl_u & kFTransposed) ? p.scale_b : p.scale_a, *fpm2 = (fl_u & kFTransposed) ? p.scale_a : p.scale_b;
+            float nanv;
+            uint32_t fs1, fs2;
+            const uint32_t fod = (uint32_t)od;
+            if constexpr (BN == 128) {
+                FP8MI_GEMM256_LOOP_FUSED_N128();
+            } else {
+                FP8MI_GEMM256_LOOP_FUSED();
+            }
+            (void)t0; (void)t1; (void)fs1; (void)fs2;
+            t = f32x4{nanv, 0.0f, 0.0f, 0.0f};
+            STAMP256(2); STAMP256(3);
+        } else
+#endif
+        {
+        FP8MI_G256_SETUP();
+        const TabRegs tabs = load_tables(p, fl_l, m0 + wm0, n0 + wn0, G::kCols, lane_l);   // in flight under the K loop, stored to the LDS behind it
         f32x32 acc4, acc5, acc6, acc7;   // fragment rows 4..7, pinned by the asm to a[128:255] (BN = 256) / a[64:127] (BN = 128: acc4, acc5)
         if (pass == 0) {
             if constexpr (BN == 128) {
@@ -377,7 +421,7 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
         store_tables(fl, tabs, tabw, lane_e);
         lds_cf32 *tab = (lds_cf32 *)(lds_void *)tabw;
         const float sr = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tabw[512])));
-        f32x4 t = epilogue_half_any<G::kCols>(p, fl, sr, dump, tab, 0, m_wave, n_wave, ldc_e, rows_ok, cols_ok, lane_e);
+        t = epilogue_half_any<G::kCols>(p, fl, sr, dump, tab, 0, m_wave, n_wave, ldc_e, rows_ok, cols_ok, lane_e);
         if (pass == 0) STAMP256(3);
         if constexpr (BN == 128) {
             FP8MI_GEMM256_DUMP_HI_N128();
@@ -386,6 +430,7 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
         }
         (void)acc6; (void)acc7;
         t += epilogue_half_any<G::kCols>(p, fl, sr, dump, tab, 1, m_wave, n_wave, ldc_e, rows_ok, cols_ok, lane_e);
+        }
         if (!(flags & kFNanZero) || pass == 1) break;
         const float sum = (t[0] + t[1]) + (t[2] + t[3]);
         if (sum != sum) *flag = 1;

@@ -44,6 +44,7 @@ PRODUCT = dict(
     pf=2,             # > 0: each step one L2 prefetch instruction per wave for the stage `pf` steps ahead of the DMA's (see pf_group)
     pf_at=56,         # index of the MFMA after which it is issued (behind the step's last DMA)
     pf_stagger=0,     # > 0: wave w issues it pf_stagger * (3 - w) MFMAs earlier (needs the kernel's per-wave split of the lines)
+    wave_delay=0,     # > 0: behind the step's barrier wave w idles w * wave_delay cycles (see wave_delay_group)
     # timing-only ablations (wrong results): which parts of the steady-state step are left out
     no_vmwait=False, no_dma=False, no_barrier=False, no_reads=False, no_mfma=False,
 )
@@ -69,6 +70,14 @@ VARIANTS = {
     19: dict(pf_at=56),              # + the kernel's per-wave split of the prefetch lines (kSplitPf)
     20: dict(pf_stagger=12),         # ... issued at MFMA 20 / 32 / 44 / 56 by wave 0 / 1 / 2 / 3
     21: dict(pf_stagger=4),
+    # round 3: de-phase the four waves behind the step's barrier (wave w idles w x wave_delay cycles), so that their stage DMA
+    # instructions reach the CU's one address path one after the other instead of together
+    22: dict(wave_delay=16),
+    23: dict(wave_delay=24),
+    24: dict(wave_delay=32),
+    25: dict(wave_delay=48),
+    26: dict(wave_delay=32, dma_every=2),
+    27: dict(wave_delay=24, dma_every=4),
 }
 P = dict(PRODUCT)
 
@@ -128,6 +137,18 @@ def pf_group():
             "buffer_load_dword v119, %[pfoff], %[rpf], %[t1] offen"]
 
 
+def wave_delay_group():
+    """wave w (%[wave]) idles about w * P['wave_delay'] cycles: a counted loop of s_nop (the barrier releases all four waves in the
+    same cycle; left alone they reach every DMA instruction of the step together and queue in the CU's address path)"""
+    n = max(P["wave_delay"] - 12, 4)   # the loop's own SALU + branch cost ~12 cycles per trip
+    nops = []
+    while n > 0:
+        k = min(n, 8)
+        nops.append(f"s_nop {k - 1}")
+        n -= k
+    return ["s_mov_b32 %[t1], %[wave]", "4:", "s_cmp_eq_u32 %[t1], 0", "s_cbranch_scc1 5f"] + nops + ["s_sub_u32 %[t1], %[t1], 1", "s_branch 4b", "5:"]
+
+
 def swap_slots():
     out = []
     for r in ("alo", "ahi", "blo", "bhi"):
@@ -158,6 +179,8 @@ def step(dma, reads):
         post[BARRIER_AFTER] += ["s_waitcnt lgkmcnt(0)" if P["no_vmwait"] else f"s_waitcnt vmcnt({vm}) lgkmcnt(0)"]
         if not P["no_barrier"]:
             post[BARRIER_AFTER] += ["s_barrier"]
+        if P["wave_delay"] and dma:
+            post[BARRIER_AFTER] += wave_delay_group()
         for tn in range(TN - 1):  # W fragment tn is dead behind its row; its re-read also has to sit behind the barrier
             post[max(8 * tn + 7, BARRIER_AFTER)] += rdW(tn, "n")
         for tm in range(8):
@@ -288,12 +311,82 @@ def pipelined2():
     return L
 
 
+# ---- fused tail (round 3): the epilogue of the common case runs UNDER the last K-step's MFMAs, straight from the AGPRs -----------
+# The LDS-dump epilogue costs 11.4 k cycles per 256x256 tile (in-kernel stamps: dump, read back, scale, convert, store with one wave per
+# SIMD and nothing to hide the latencies) behind a K loop of 64 k.  For per-tensor scales without bias / scale_result on tiles that are
+# whole in N the same arithmetic - (acc * s1) * s2, one packed convert, the ring kernels' rounding sequence - is done in registers:
+#   * a fragment pair (tn, tn+1; tm) is final once both its MFMAs of the last step have run; `v_accvgpr_read` copies its 8 accumulators
+#     into the registers of W fragments the step has finished with;
+#   * 4 `v_permlane16_swap_b32` exchange lane-group rows between the two fragments so that every lane holds 8 CONSECUTIVE columns
+#     (lane group fg: columns (tn + (fg & 1)) * 16 + (fg >> 1) * 8 ..+7 of row tm * 16 + fr) - one 16-byte store per lane (two for
+#     fp32), 64 contiguous bytes per row and instruction;
+#   * 8 packed multiplies, 4 packed converts, one `buffer_store_dwordx4 ... nt` whose descriptor range-checks the rows of a ragged
+#     last m-tile; the row block of tm travels in the scalar offset;
+#   * the ops of pair p are issued from MFMA 16 p + 16 on, FUSED_Q per MFMA (an 8-pass MFMA leaves 7 issue slots), the rest behind the
+#     last MFMA: the tail is bound by ~27 VALU ops per (pair, tm) instead of by LDS round trips.
+# NaN bytes (reference: decode to 0): the sum of the fragments (pair p, tm in p's own row blocks) covers every row block and every
+# column block of the wave tile; a NaN byte poisons a whole row or column of accumulators, so a NaN in that sum proves one took part.
+FUSED_Q = 7
+
+
+def fused_item(p, tm, out):
+    tn = 2 * p
+    S = 128 + 8 * ((p * 8 + tm) % 2)   # two alternating sets of 8 temporaries in the registers of W fragments 0 and 1 (dead by then)
+    ops = []
+    if tm == 0:
+        ops.append("s_mov_b32 %[t0], 0")
+    ops += [f"v_accvgpr_read_b32 v{S + j}, a{ACC(tn, tm) + j}" for j in range(4)]
+    ops += [f"v_accvgpr_read_b32 v{S + 4 + j}, a{ACC(tn + 1, tm) + j}" for j in range(4)]
+    ops += [f"v_permlane16_swap_b32 v{S + j}, v{S + 4 + j}" for j in range(4)]
+    sel = (tm in (2 * p, 2 * p + 1)) if TN == 8 else (tm // 4 == p)
+    if sel:
+        ops += [f"v_pk_add_f32 v[118:119], v[118:119], v[{S + 2 * j}:{S + 2 * j + 1}]" for j in range(4)]
+    ops += [f"v_pk_mul_f32 v[{S + 2 * j}:{S + 2 * j + 1}], v[{S + 2 * j}:{S + 2 * j + 1}], v[120:121]" for j in range(4)]
+    ops += [f"v_pk_mul_f32 v[{S + 2 * j}:{S + 2 * j + 1}], v[{S + 2 * j}:{S + 2 * j + 1}], v[122:123]" for j in range(4)]
+    if out == "f32":
+        ops += [f"buffer_store_dwordx4 v[{S}:{S + 3}], %[voff], %[rc], %[t0] offen offset:{p * 128} nt",
+                f"buffer_store_dwordx4 v[{S + 4}:{S + 7}], %[voff], %[rc], %[t0] offen offset:{p * 128 + 16} nt"]
+    else:
+        cvt = "v_cvt_pk_bf16_f32" if out == "bf16" else "v_cvt_pk_f16_f32"
+        ops += [f"{cvt} v{S + j}, v{S + 2 * j}, v{S + 2 * j + 1}" for j in range(4)]
+        ops += [f"buffer_store_dwordx4 v[{S}:{S + 3}], %[voff], %[rc], %[t0] offen offset:{p * 64} nt"]
+    ops.append("s_add_u32 %[t0], %[t0], %[srow]")
+    return ops
+
+
+def fused_last_step(out):
+    NM, LR = 8 * TN, 8 * (TN - 1)
+    pre = [[] for _ in range(NM)]
+    for tm in range(8):
+        pre[tm].append(f"s_waitcnt lgkmcnt({min(15, 2 * (7 - tm) + 2)})")
+    pre[LR].append("s_waitcnt lgkmcnt(0)")
+    queue = []   # (index of the MFMA the op may follow, op)
+    for p in range(TN // 2):
+        for tm in range(8):
+            queue += [(16 * p + 16, op) for op in fused_item(p, tm, out)]
+    L = ["v_mov_b32 v118, 0", "v_mov_b32 v119, 0",
+         "v_mov_b32 v120, %[s1]", "v_mov_b32 v121, %[s1]", "v_mov_b32 v122, %[s2]", "v_mov_b32 v123, %[s2]"]
+    qi = 0
+    for i in range(NM):
+        L += pre[i]
+        L.append(mfma(i // 8, i % 8))
+        n = 0
+        while qi < len(queue) and queue[qi][0] <= i and n < FUSED_Q:
+            L.append(queue[qi][1]); qi += 1; n += 1
+    L += ["s_nop 7", "s_nop 7"]
+    L += [op for _, op in queue[qi:]]
+    L += ["v_add_f32 %[nanv], v118, v119"]
+    return L
+
+
 def zero_acc():
     return [f"v_accvgpr_write_b32 a{i}, 0" for i in range(32 * TN)]
 
 
-def pipelined():
+def pipelined(fused=None):
     L = []
+    if fused:   # the two per-tensor scales: scalar loads that land under the first K-steps (their first use is in the tail)
+        L += ["s_load_dword %[s1], %[pm1], 0x0", "s_load_dword %[s2], %[pm2], 0x0"]
     # prologue: stages 0 and 1 in flight, accumulators cleared under their latency
     for g in dma_block("%[m0_c]", "%[k2]"):
         L += g
@@ -310,6 +403,14 @@ def pipelined():
     L += step(True, True)
     L += ["s_sub_u32 %[nloop], %[nloop], 1", "s_cmp_lg_u32 %[nloop], 0", "s_cbranch_scc1 1b", "2:"]
     L += step(False, True)
+    if fused:
+        # one statement, three tails (the output type is a launch-time switch; as three statements hipcc kept a private copy of
+        # every read-write operand per statement and spilled them): FP8MI_F32 = 0, FP8MI_F16 = 1, FP8MI_BF16 = 2
+        L += ["s_cmp_eq_u32 %[od], 2", "s_cbranch_scc1 10f", "s_cmp_eq_u32 %[od], 1", "s_cbranch_scc1 11f"]
+        L += fused_last_step("f32") + ["s_branch 12f", "10:"]
+        L += fused_last_step("bf16") + ["s_branch 12f", "11:"]
+        L += fused_last_step("f16") + ["12:"]
+        return L
     L += step(False, False)
     L += ["s_nop 7", "s_nop 7", "s_nop 7", "s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]
     L += dump(range(4))
@@ -358,13 +459,15 @@ def scrubbed():
     return L
 
 
-def emit(name, lines, scrub):
+def emit(name, lines, scrub, fused=False):
     print(f"#define {name}() \\")
     print("    asm volatile( \\")
     for l in lines:
         print(f'        "{l}\\n\\t" \\')
     nblk = TN // 2   # fragment rows 4..7 (16 TN AGPRs) as 32-float operands: acc4.. pinned to a[16 TN + 32 i : + 31]
-    outs = [f'"={{a[{16 * TN + 32 * i}:{16 * TN + 32 * i + 31}]}}"(acc{4 + i})' for i in range(nblk)]
+    outs = [] if fused else [f'"={{a[{16 * TN + 32 * i}:{16 * TN + 32 * i + 31}]}}"(acc{4 + i})' for i in range(nblk)]
+    if fused:
+        outs += ['[nanv] "=&v"(nanv)', '[s1] "=&s"(fs1)', '[s2] "=&s"(fs2)']
     outs += ['[alo_c] "+v"(alo_c)', '[ahi_c] "+v"(ahi_c)', '[blo_c] "+v"(blo_c)', '[bhi_c] "+v"(bhi_c)',
             '[alo_n] "+v"(alo_n)', '[ahi_n] "+v"(ahi_n)', '[blo_n] "+v"(blo_n)', '[bhi_n] "+v"(bhi_n)',
             '[k2] "+s"(k2)', '[m0_c] "+s"(m0_c)', '[m0_n] "+s"(m0_n)', '[nloop] "+s"(nloop)', '[t0] "=&s"(t0)', '[t1] "=&s"(t1)']
@@ -372,7 +475,10 @@ def emit(name, lines, scrub):
         outs += ['[vt0] "=&v"(vt0)', '[vt1] "=&v"(vt1)']
     ins = ['[va0] "v"(va0)', '[vb0] "v"(vb0)', '[vscale] "v"(vscale)', '[ra] "s"(ra)', '[rb] "s"(rb)', '[sa] "s"(sa)', '[sb] "s"(sb)',
            '[drow] "v"(drow)', '[dkey] "v"(dkey)', '[pfoff] "v"(pfoff)', '[rpf] "s"(rpf)', '[klast] "s"(klast)', '[wave] "s"(wave_s)']
-    clob = [f'"v{i}"' for i in range(118, 256)] + [f'"a{i}"' for i in range(16 * TN)] + ['"scc"', '"memory"']
+    # m0 is written by the DMA groups (s_mov_b32 / s_add_u32 m0): declared, so that LLVM never keeps an M0 initialisation of its own live across the statement
+    if fused:
+        ins += ['[rc] "s"(frc)', '[voff] "v"(fvoff)', '[srow] "s"(fsrow)', '[pm1] "s"(fpm1)', '[pm2] "s"(fpm2)', '[od] "s"(fod)']
+    clob = [f'"v{i}"' for i in range(118, 256)] + [f'"a{i}"' for i in range(32 * TN if fused else 16 * TN)] + ['"m0"', '"scc"', '"memory"']
     print("        : " + ", ".join(outs) + " \\")
     print("        : " + ", ".join(ins) + " \\")
     print("        : " + ", ".join(clob) + ")")
@@ -404,6 +510,13 @@ if __name__ == "__main__":
     emit_dump_hi("FP8MI_GEMM256_DUMP_HI_N128")
     TN = 8
     print("#ifdef FP8MI_DIAG  // schedule variants and timing-only ablations (libfp8mi_diag.so, kernel ids 80 + variant)")
+    print("// fused tail (epilogue from the AGPRs under the last K-step; measured SLOWER than the LDS dump: its 64-byte row segments store at")
+    print("// ~290 cycles per instruction and wave against ~200 for whole 256-byte rows, profiles/r03_tail_probe.txt) - FP8MI_DEBUG bit 2 selects it")
+    emit("FP8MI_GEMM256_LOOP_FUSED", pipelined(True), False, fused=True)
+    TN = 4
+    P.clear(); P.update(PRODUCT)
+    emit("FP8MI_GEMM256_LOOP_FUSED_N128", pipelined(True), False, fused=True)
+    TN = 8
     for v, over in sorted(VARIANTS.items()):
         P.clear(); P.update(PRODUCT); P.update(over)
         print(f"// variant {v}: {over}")

@@ -49,8 +49,38 @@ NAN_MODE = _l.NAN_ZERO          # reference decode: NaN bytes are 0.0
 ENCODE_MODE = _l.ENC_REFERENCE  # reference encode rules
 
 
+# Conversions made INSIDE this module never involve an fp8 dtype, so they use the C-level Tensor.to: while the
+# monkey-patch is installed `tensor.to(...)` is fp8_mps_patch._metal_tensor_to, a Python function that parses the
+# overloads of .to before it can decide that the call is none of its business (~3 us per call on the hot path).
+_TO = torch._C.TensorBase.to
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(device):
+    """hipStream_t (as int) of torch's current stream on `device`.  The raw accessor skips the construction of a
+    torch.cuda.Stream object (1.5 us of the ~4 us this module adds to a call; tools/time_callsite.py)."""
+    if _raw_stream is not None:
+        return _raw_stream(device.index if device.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class _on_device:
+    """`with torch.cuda.device(dev)` only when `dev` is not already current (the context manager costs two device
+    switches and ~2 us even when it changes nothing)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        self.ctx = None if (dev.index is None or torch.cuda.current_device() == dev.index) else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
 
 
 # split-K workspaces: one per (device, stream) - launches on one stream are ordered, so they can share it; the
@@ -65,7 +95,11 @@ def _workspace(device):
     and no workspace exists yet: allocating inside a capture would put it into the graph's private pool, where later
     eager launches on the same stream handle would share it (warm the op up once before capturing; without a workspace
     the call simply does not split K)."""
-    key = (device.index, _stream(device))
+    return _workspace_on(device, _stream(device))
+
+
+def _workspace_on(device, stream):
+    key = (device.index, stream)
     ws = _workspaces.get(key)
     if ws is None:
         if torch.cuda.is_current_stream_capturing():
@@ -74,7 +108,7 @@ def _workspace(device):
             ws = _workspaces.get(key)
             if ws is None:
                 ws = torch.empty(int(_l.load().fp8mi_scaled_mm_workspace_bytes()), dtype=torch.uint8, device=device)
-                _l.check(_l.load().fp8mi_workspace_reset(ws.data_ptr(), ws.numel(), _stream(device)), "fp8mi_workspace_reset")
+                _l.check(_l.load().fp8mi_workspace_reset(ws.data_ptr(), ws.numel(), stream), "fp8mi_workspace_reset")
                 _workspaces[key] = ws
     return ws
 
@@ -84,9 +118,13 @@ def reset_workspaces():
     after a launch was aborted mid-flight (device fault, process-level error recovery) - every completed launch leaves
     them zero by itself."""
     with _workspaces_lock:
-        for (dev_index, _), ws in _workspaces.items():
+        for (dev_index, stream), ws in _workspaces.items():
             with torch.cuda.device(dev_index):
-                _l.check(_l.load().fp8mi_workspace_reset(ws.data_ptr(), ws.numel(), _stream(ws.device)), "fp8mi_workspace_reset")
+                # a workspace is ordered on the stream it is keyed by: the reset goes onto THAT stream (not the caller's
+                # current one), bracketed by device syncs so that it neither races a launch in flight nor trails the next
+                torch.cuda.synchronize(dev_index)
+                _l.check(_l.load().fp8mi_workspace_reset(ws.data_ptr(), ws.numel(), stream), "fp8mi_workspace_reset")
+                torch.cuda.synchronize(dev_index)
 
 
 def _to_device(t: torch.Tensor) -> torch.Tensor:
@@ -96,7 +134,10 @@ def _to_device(t: torch.Tensor) -> torch.Tensor:
 def _scale_arg(scale, device, rows: int, what: str):
     """-> (float32 contiguous tensor on `device`, mode).  1 element = per-tensor,
     `rows` elements (any shape, e.g. (M,1) / (1,N)) = per-row."""
-    s = scale.to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+    s = scale
+    # already what the kernel reads (the common case: a float32 device scalar or (M,1) / (1,N) column): no new tensor
+    if not (s.dtype is torch.float32 and s.device == device and s.is_contiguous()):
+        s = _TO(s, device=device, dtype=torch.float32).reshape(-1).contiguous()
     if s.numel() == 1:
         return s, _l.SCALE_TENSOR
     if s.numel() == rows:
@@ -145,29 +186,40 @@ def fp8_scaled_mm(A: torch.Tensor, B: torch.Tensor, scale_a: torch.Tensor, scale
         B = B.contiguous()
     lda = max(A.stride(0), K) if M > 1 else max(K, 1)
     ldb = max(B.stride(0), K) if N > 1 else max(K, 1)
+    return _scaled_mm_core(A, B, M, N, K, lda, ldb, dev, scale_a, scale_b, bias, scale_result, out_dtype, nan_mode,
+                           kernel, split_k, out, transposed_epilogue)
 
+
+def _scaled_mm_core(a_keep, b_keep, M, N, K, lda, ldb, dev, scale_a, scale_b, bias, scale_result, out_dtype, nan_mode,
+                    kernel, split_k, out, transposed_epilogue):
+    """Everything behind the operand checks: scales, output, epilogue arguments, ONE ctypes call.  `a_keep` / `b_keep`
+    are tensors of ANY dtype whose storage holds the (M,K) / (N,K) byte rows at data_ptr() with row strides lda / ldb
+    (the patch hands over the float8 tensors themselves: no uint8 views, no .t())."""
     sa, sa_mode = _scale_arg(scale_a, dev, M, "scale_a")
     sb, sb_mode = _scale_arg(scale_b, dev, N, "scale_b")
 
     out_dtype = torch.float32 if out_dtype is None else out_dtype
-    if out_dtype not in _DTYPE_CODE:
+    out_code = _DTYPE_CODE.get(out_dtype)
+    if out_code is None:
         raise AssertionError(f"unsupported out_dtype {out_dtype}")
     if out is not None:
         assert out.shape == (M, N) and out.dtype == out_dtype and out.device == dev, "out must be (M, N) out_dtype on A's device"
         assert N <= 1 or out.stride(1) == 1, "out needs unit column stride"
         C = out
     else:
-        C = torch.empty(M, N, dtype=out_dtype, device=dev)
+        C = torch.empty((M, N), dtype=out_dtype, device=dev)
     if M == 0 or N == 0:
         return C
     ldc = max(C.stride(0), N) if M > 1 else max(N, 1)
 
     bias_ptr, bias_code = None, _l.F32
     if bias is not None:
-        bias = bias.to(device=dev)
+        if bias.device != dev:
+            bias = _TO(bias, device=dev)
         if bias.dtype not in _DTYPE_CODE:
-            bias = bias.to(torch.float32)
-        bias = bias.reshape(-1).contiguous()
+            bias = _TO(bias, torch.float32)
+        if not bias.is_contiguous():
+            bias = bias.reshape(-1).contiguous()
         nb = M if transposed_epilogue else N
         assert bias.numel() == nb, f"bias has {bias.numel()} elements; expected {nb}"
         bias_ptr, bias_code = bias.data_ptr(), _DTYPE_CODE[bias.dtype]
@@ -175,21 +227,49 @@ def fp8_scaled_mm(A: torch.Tensor, B: torch.Tensor, scale_a: torch.Tensor, scale
         bias_code |= _l.EPILOGUE_TRANSPOSED
     sr_ptr = None
     if scale_result is not None:
-        scale_result = scale_result.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        if not (scale_result.dtype is torch.float32 and scale_result.device == dev and scale_result.is_contiguous()):
+            scale_result = _TO(scale_result, device=dev, dtype=torch.float32).reshape(-1).contiguous()
         assert scale_result.numel() == 1, "scale_result must have one element"
         sr_ptr = scale_result.data_ptr()
 
     lib = _l.load()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
+        stream = _stream(dev)
         # a workspace only where split-K can apply: more than one row, K deep enough to slice
-        ws = _workspace(dev) if (split_k != 1 and M > 1 and K >= 1024) else None
+        ws = _workspace_on(dev, stream) if (split_k != 1 and M > 1 and K >= 1024) else None
         rc = lib.fp8mi_scaled_mm_ws(
-            A.data_ptr(), B.data_ptr(), C.data_ptr(), sa.data_ptr(), sb.data_ptr(), bias_ptr, sr_ptr,
-            M, N, K, lda, ldb, ldc, sa_mode, sb_mode, _DTYPE_CODE[out_dtype], bias_code,
+            a_keep.data_ptr(), b_keep.data_ptr(), C.data_ptr(), sa.data_ptr(), sb.data_ptr(), bias_ptr, sr_ptr,
+            M, N, K, lda, ldb, ldc, sa_mode, sb_mode, out_code, bias_code,
             NAN_MODE if nan_mode is None else nan_mode, kernel, split_k if ws is not None else 1,
-            ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream(dev))
-    _l.check(rc, "fp8mi_scaled_mm")
+            ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, stream)
+    if rc:
+        _l.check(rc, "fp8mi_scaled_mm")
     return C
+
+
+def scaled_mm_colmajor(input: torch.Tensor, other: torch.Tensor, scale_a, scale_b, *, bias=None, scale_result=None,
+                       out_dtype=None):
+    """The call torch._scaled_mm makes, without intermediate tensors: `input` (M,K) row-major and `other` (K,N) in the
+    column-major layout torch mandates, both float8_e4m3fn or uint8 ON A HIP DEVICE.  `other`'s storage then already is
+    the (N,K) row-major operand the kernels read (fp8_mps_patch.py:77-86 makes it with .t().contiguous()), so the
+    pointers and strides are passed as they are.  Returns None when the layout is anything else (the caller falls back
+    to fp8_scaled_mm, which copies)."""
+    if input.dim() != 2 or other.dim() != 2:
+        return None
+    M, K = input.shape
+    K2, N = other.shape
+    if K2 != K or other.device != input.device:
+        return None
+    sa0, sa1 = input.stride()
+    sb0, sb1 = other.stride()
+    if not (K == 0 or M == 0 or (sa1 == 1 and sa0 >= K) or (M == 1 and sa1 == 1)):
+        return None
+    if not (K == 0 or N == 0 or (sb0 == 1 and sb1 >= K) or (N == 1 and sb0 == 1)):
+        return None
+    lda = max(sa0, K) if M > 1 else max(K, 1)
+    ldb = max(sb1, K) if N > 1 else max(K, 1)
+    return _scaled_mm_core(input, other, M, N, K, lda, ldb, input.device, scale_a, scale_b, bias, scale_result, out_dtype,
+                           None, _l.KERNEL_AUTO, 0, None, False)
 
 
 def fp8_dequantize(input: torch.Tensor, scale: torch.Tensor | None = None,
@@ -211,11 +291,11 @@ def fp8_dequantize(input: torch.Tensor, scale: torch.Tensor | None = None,
         return out
     s_ptr = None
     if scale is not None:
-        scale = scale.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        scale = _TO(scale, device=dev, dtype=torch.float32).reshape(-1).contiguous()
         assert scale.numel() == 1, "scale must be a scalar"
         s_ptr = scale.data_ptr()
     lib = _l.load()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib.fp8mi_dequant(src.data_ptr(), out.data_ptr(), s_ptr, count, _DTYPE_CODE[out_dtype], _stream(dev))
     _l.check(rc, "fp8mi_dequant")
     return out
@@ -240,7 +320,7 @@ def fp8_encode(input: torch.Tensor, encode_mode: int | None = None) -> torch.Ten
     if count == 0:
         return out
     lib = _l.load()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib.fp8mi_encode(inp.data_ptr(), _DTYPE_CODE[inp.dtype], out.data_ptr(), None, count,
                               ENCODE_MODE if encode_mode is None else encode_mode, _stream(dev))
     _l.check(rc, "fp8mi_encode")
@@ -258,7 +338,7 @@ def fp8_quantize(input: torch.Tensor, encode_mode: int | None = None):
     out = torch.empty(inp.shape, dtype=torch.uint8, device=dev)
     scales = torch.empty(2, dtype=torch.float32, device=dev)
     lib = _l.load()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib.fp8mi_quantize(inp.data_ptr(), _DTYPE_CODE[inp.dtype], out.data_ptr(), scales.data_ptr(),
                                 inp.numel(), ENCODE_MODE if encode_mode is None else encode_mode, _stream(dev))
     _l.check(rc, "fp8mi_quantize")
@@ -291,7 +371,7 @@ def fp8_amax(input: torch.Tensor) -> torch.Tensor:
     dev = inp.device
     out = torch.empty(1, dtype=torch.float32, device=dev)
     lib = _l.load()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib.fp8mi_amax(inp.data_ptr(), _DTYPE_CODE[inp.dtype], out.data_ptr(), inp.numel(), _stream(dev))
     _l.check(rc, "fp8mi_amax")
     return out

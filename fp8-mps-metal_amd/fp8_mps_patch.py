@@ -64,9 +64,15 @@ def _is_e4m3(dtype):
     return dtype is not None and dtype == _E4M3
 
 
+_native_mod = None
+
+
 def _native():
-    import fp8_mi355x_native  # lazy, like the reference's `import fp8_mps_native` (:74)
-    return fp8_mi355x_native
+    global _native_mod
+    if _native_mod is None:
+        import fp8_mi355x_native  # lazy, like the reference's `import fp8_mps_native` (:74)
+        _native_mod = fp8_mi355x_native
+    return _native_mod
 
 
 def _is_dev(device) -> bool:
@@ -113,17 +119,21 @@ def _metal_scaled_mm(input, other, *args, out_dtype=None, scale_a=None, scale_b=
                                    bias=bias, scale_result=scale_result, use_fast_accum=use_fast_accum)
 
     native = _native()
-    a = input if input.dtype == torch.uint8 else input.view(torch.uint8)
-    o = other if other.dtype == torch.uint8 else other.view(torch.uint8)
-    # other is (K,N); the kernels want the (N,K) row-major operand.  For the
-    # column-major `other` torch mandates, .t() IS that operand - no copy.
-    b_nk = o.t()
     dev = input.device
     if scale_a is None:
         scale_a = _ones(dev)
     if scale_b is None:
         scale_b = _ones(dev)
-    return native.fp8_scaled_mm_auto(a, b_nk, scale_a, scale_b, bias=bias, scale_result=scale_result,
+    # other is (K,N); the kernels want the (N,K) row-major operand.  For the column-major `other` torch mandates the
+    # storage IS that operand: pointers and strides go down as they are - no uint8 views, no .t() (each a tensor
+    # construction of ~1 us on a path whose kernels take 5-15 us)
+    r = native.scaled_mm_colmajor(input, other, scale_a, scale_b, bias=bias, scale_result=scale_result, out_dtype=out_dtype)
+    if r is not None:
+        return r
+    # any other layout (row-major `other`, strided rows): the general entry makes the operands contiguous
+    a = input if input.dtype == torch.uint8 else input.view(torch.uint8)
+    o = other if other.dtype == torch.uint8 else other.view(torch.uint8)
+    return native.fp8_scaled_mm_auto(a, o.t(), scale_a, scale_b, bias=bias, scale_result=scale_result,
                                      out_dtype=out_dtype)
 
 

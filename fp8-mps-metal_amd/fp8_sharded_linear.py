@@ -22,7 +22,11 @@ Why it shards this way (MI355X-first):
     bias per output ROW (= weight row) and applies the scales in the order of
     the untransposed product, and every tile kernel adds the K-steps of an
     element in the same order - so a sharded linear returns the bits the
-    unsharded fused `_scaled_mm` returns (tested, bf16 output included).
+    unsharded fused `_scaled_mm` returns WHEN BOTH CALLS RUN UNSPLIT TILE
+    KERNELS (tested, bf16 output included).  The sharded call always does
+    (`split_k=1`); an unsharded AUTO call with few tokens (M = 1, the few-rows
+    and skinny kernels, or a split-K launch) sums K in another order and then
+    agrees only to the oracle bound, not bit for bit.
   * xGMI is point-to-point (7 links per GPU); the all-gather (each rank's slab
     to all 7 peers at once) dominates this shape, so it is pipelined against
     the GEMM: the weight rows are dealt out CHUNK-CYCLICALLY - chunk j of every
@@ -31,9 +35,10 @@ Why it shards this way (MI355X-first):
     implies is applied once, at weight-load time (`shard_rows`), and it is
     chosen so that gathered order == global row order: the result needs no
     un-permutation.
-  * Nothing is created per call besides the output: the side stream and the
-    per-chunk events live in the module, so a forward is `chunks` launches +
-    `chunks` collectives and can be captured into a HIP graph.
+  * Nothing is created per call besides the output - and not even that when
+    the caller passes its own gather buffer (`forward(x, sa, out_t=...)`): the
+    side stream and the per-chunk events live in the module, so a forward is
+    `chunks` launches + `chunks` collectives and can be captured into a HIP graph.
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).  The
 local product is the HIP kernel; `mm` can be injected so that the sharding /
@@ -117,12 +122,18 @@ class ColumnShardedFP8Linear:
         b = None if bias is None else bias.reshape(-1)[rows]
         return cls(weight_u8_full[rows].contiguous(), sb, b, N=N, group=group, chunks=chunks, **kw)
 
-    def forward(self, x_u8: torch.Tensor, scale_a: torch.Tensor) -> torch.Tensor:
+    def forward(self, x_u8: torch.Tensor, scale_a: torch.Tensor, out_t: torch.Tensor | None = None) -> torch.Tensor:
         """x_u8 (M,K) uint8 replicated on every rank -> (M,N) `out_dtype`
-        (a transposed view of the gathered (N,M) buffer), identical on every rank."""
+        (a transposed view of the gathered (N,M) buffer), identical on every rank.
+        out_t: optional caller-owned gather buffer, contiguous (N, M) of `out_dtype` on x's device (C^T): with it a
+        forward allocates nothing (a forward captured into a HIP graph then owns no memory of the graph's pool, and a
+        serving loop can ping-pong two buffers); the returned tensor is its `.t()` view."""
         M = x_u8.shape[0]
         dev = x_u8.device
-        out_t = torch.empty(self.N, M, dtype=self.out_dtype, device=dev)  # C^T
+        if out_t is None:
+            out_t = torch.empty(self.N, M, dtype=self.out_dtype, device=dev)  # C^T
+        elif not (out_t.shape == (self.N, M) and out_t.dtype == self.out_dtype and out_t.device == dev and out_t.is_contiguous()):
+            raise ValueError(f"out_t must be a contiguous ({self.N}, {M}) {self.out_dtype} tensor on {dev}")
         grouped = dist.is_initialized()          # a 1-rank group still takes the collective path
         on_gpu = dev.type == "cuda" and grouped
         if on_gpu and self._comm_stream is None:

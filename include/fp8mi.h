@@ -193,6 +193,13 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C,
 int fp8mi_dequant(const uint8_t *in, void *out, const float *scale,
                   int64_t count, int out_dtype, void *stream);
 
+/* The same entry point under the name SURVEY.md 8(b) item 2 gives it (the half output of fp8_to_half_kernel is the
+ * default use; out_dtype still selects F16 / F32 / BF16).  Two deviations from 8(b) as written, both on purpose:
+ * the symbol was shortened to fp8mi_dequant (this alias keeps the contract's name linkable), and every leading
+ * dimension / count in this header is int64_t where 8(b) says `int` (a (M,K) slab of a > 2 GiB buffer needs it). */
+int fp8mi_dequant_f16(const uint8_t *in, void *out, const float *scale_or_null,
+                      int64_t count, int out_dtype, void *stream);
+
 /*
  * out[i] = enc( float32(in[i]) * prescale )            (prescale NULL = no multiply)
  *

@@ -52,7 +52,7 @@ def _fused_mm_reference(x_u8, W_u8, sa, sb, bias, out_dtype):
     return torch.from_numpy(r.astype(np.float32)).to(out_dtype)
 
 
-def _worker(rank, world, port, chunks, per_row, with_bias, out_dtype, q):
+def _worker(rank, world, port, chunks, per_row, with_bias, out_dtype, q, geometry=None):
     for p in (PKG, ORACLE):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -62,7 +62,7 @@ def _worker(rank, world, port, chunks, per_row, with_bias, out_dtype, q):
         import fp8_oracle as o
         from fp8_sharded_linear import ColumnShardedFP8Linear, shard_rows
         rng = np.random.default_rng(42)  # same data on every rank
-        M, K, N = 24, 64, 32 * world
+        M, K, N = geometry or (24, 64, 32 * world)
         x = torch.from_numpy(rng.integers(0, 256, size=(M, K), dtype=np.uint8))
         W = torch.from_numpy(rng.integers(0, 256, size=(N, K), dtype=np.uint8))
         sa = torch.tensor([0.03])
@@ -86,6 +86,15 @@ def _worker(rank, world, port, chunks, per_row, with_bias, out_dtype, q):
         ok = ok and bool(np.all(np.abs(y.float().numpy() - ref) <= 4e-6 * bound + eps * np.abs(ref) + 1e-30))
         # a second forward reuses the module's state (streams / events / views) and gives the same bits
         ok = ok and torch.equal(lin(x, sa), y)
+        # ... and so does one into a caller-owned gather buffer (no allocation in the forward), whose storage it returns
+        buf = torch.full((N, M), float("nan"), dtype=out_dtype)
+        y2 = lin(x, sa, out_t=buf)
+        ok = ok and y2.data_ptr() == buf.data_ptr() and torch.equal(y2, y)
+        try:
+            lin(x, sa, out_t=torch.empty(M, N, dtype=out_dtype))
+            ok = False
+        except ValueError:
+            pass
         # identical on every rank
         g = [torch.empty_like(y.contiguous()) for _ in range(world)]
         dist.all_gather(g, y.contiguous())
@@ -113,12 +122,35 @@ def test_sharded_linear_world2(chunks, per_row, with_bias, out_dtype):
     assert got == [(r, True, True) for r in range(world)]
 
 
+@pytest.mark.parametrize("world,chunks", [(8, 2), (8, 4), (4, 2), (4, 4)])
+def test_sharded_linear_c4_partition_geometry(world, chunks):
+    """BASELINE config C4's partition: N = 12288 weight rows over 8 (and 4) ranks, 2 and 4 chunk-cyclic row chunks per rank
+    (nc = 768 / 384 at world 8) - the geometry the driver's multi-GPU bench runs, executed here rank for rank over gloo with
+    small M and K: every rank's slab lands in its slot, gathered order equals global order, the result equals the unsharded
+    fused product bit for bit (bf16, per-row scales, bias) and is identical on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    geometry = (8, 32, 12288)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, chunks, True, True, torch.bfloat16, q, geometry)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0, f"rank process exited with {p.exitcode}"
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert got == [(r, True, True) for r in range(world)]
+
+
 def test_shard_rows_layout():
     sys.path.insert(0, PKG)
     from fp8_sharded_linear import shard_rows
     assert shard_rows(8, 2, 0).tolist() == [0, 1, 2, 3] and shard_rows(8, 2, 1).tolist() == [4, 5, 6, 7]
     assert shard_rows(8, 2, 0, chunks=2).tolist() == [0, 1, 4, 5]
     assert shard_rows(8, 2, 1, chunks=2).tolist() == [2, 3, 6, 7]
+    # C4: rank 3 of 8, two chunks of 768 rows: global rows 3*768.. and 8*768 + 3*768..
+    r = shard_rows(12288, 8, 3, chunks=2)
+    assert r.numel() == 1536 and r[0] == 2304 and r[767] == 3071 and r[768] == 6144 + 2304 and r[-1] == 6144 + 3071
     with pytest.raises(ValueError):
         shard_rows(10, 4, 0)
 

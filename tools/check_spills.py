@@ -25,10 +25,20 @@ with tempfile.TemporaryDirectory() as td:
             print(f"{f:20s} vgpr {vgpr:3d}  vgpr_spill {vspill:3d}  sgpr_spill {sspill:3d}  scratch {priv:4d}  {short}{flag}")
             bad += 1 if over else 0
         if f == "fp8mi_gemm256.hip":
+            # one wave per SIMD is a CORRECTNESS assumption of this kernel (the wave's quadrant, staging rows and dump slot come
+            # from HW_ID.SIMD_ID): it holds only while a wave's VGPR + AGPR allocation exceeds half of the SIMD's 512 registers
+            for m in re.finditer(r"\.agpr_count:\s+(\d+).*?\.name:\s+(\S*gemm256_kernel\S*).*?\.vgpr_count:\s+(\d+)", asm, flags=re.S):
+                agpr, total = int(m.group(1)), int(m.group(3))   # .vgpr_count is the unified total (arch VGPRs + AGPRs, aligned)
+                ok = total > 256
+                kname = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", m.group(2))[:60]
+                print(f"{f:20s} registers {total:3d} (agpr {agpr:3d})  {kname}{'' if ok else '  <-- <= 256: TWO WAVES MAY SHARE A SIMD'}")
+                bad += 0 if ok else 1
             # its accumulators live in a[0:255] by hand (csrc/gen/gen_gemm256_loop.py); the only AGPR instructions allowed are
             # the generator's: MFMAs, `v_accvgpr_write_b32 aN, 0` and `ds_write_b128 ..., a[..]`.  Anything else means hipcc
             # parked or moved values in AGPRs around the hand-written loop.
-            n = len(re.findall(r"v_accvgpr_read|v_accvgpr_mov|v_accvgpr_write_b32 a\d+, [vs]", asm))
+            # (the fused tail's own `v_accvgpr_read_b32 v128..v143, aN` are the generator's too)
+            n = len(re.findall(r"v_accvgpr_mov|v_accvgpr_write_b32 a\d+, [vs]", asm))
+            n += sum(1 for m in re.finditer(r"v_accvgpr_read_b32 v(\d+)", asm) if not 128 <= int(m.group(1)) <= 143)
             print(f"{f:20s} compiler-generated AGPR traffic: {n} instruction(s){'  <-- AGPR' if n else ''}")
             bad += 1 if n else 0
 print(f"{bad} kernel(s) spill beyond what is tolerated")
