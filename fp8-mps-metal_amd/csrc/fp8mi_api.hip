@@ -85,6 +85,18 @@ static int choose_kernel(const MMParams &p)
         const int64_t t64 = (p.N + 63) / 64, cus = fp8mi_cu_count();
         if (p.M <= 4 || (p.K > 4096 && t64 < (3 * cus) / 4)) return FP8MI_KERNEL_GEMV_MX;
     }
+    if (p.M >= 9 && p.M <= 128 && p.K >= 2048 && p.ws && p.split != 1 && fp8mi_gemm_supported(p) && (double)p.N * (double)p.K >= 12.0 * 1048576.0) {
+        // The small-batch regime on the SMALL tile kernels with the automatic K split (round 3; tools/sweep_decode.py on MI355X, six (K, N)
+        // from 4096^2 to 14336 x 4096, M = 9 .. 128): 32x64 tiles for M <= 32 (K=14336 N=4096: 12.9-13.2 us against 16.5-17.2 on 64x128 x 8
+        // slices; K=12288 N=3072 11.4 against 15.8-16.2; K=N=4096 8.2-8.4 against the skinny kernel's 8.5-10.2), 64x64 tiles for M <= 64
+        // (14.3-14.9 against 17.2-17.4) and on to M = 128 while 128x64 tiles would leave half the CUs idle (K=N=4096 M=96: 9.5 against 13.2;
+        // K=N=8192 M=96: 19.0 against 22.5) - except M > 96 against K > 8192, where 128x64 x split stays 3-6 % ahead.
+        const int64_t cus = fp8mi_cu_count(), t64 = ((p.M + 127) / 128) * ((p.N + 63) / 64);
+        if (p.M <= 32) return FP8MI_KERNEL_GEMM_32x64;
+        if (p.M <= 64 && (double)p.N * (double)p.K <= 16.0 * 1048576.0) return FP8MI_KERNEL_GEMM_32x64;   // (K=N=4096, M=48-64: 8.3 against 9.4 us)
+        if (p.M <= 64) return FP8MI_KERNEL_GEMM_64x64;
+        if (t64 <= cus / 2 && !(p.M > 96 && p.K > 8192)) return FP8MI_KERNEL_GEMM_64x64;
+    }
     if (p.M >= 2 && p.M <= 48 && fp8mi_skinny_supported(p)) {
         // measured (tools/sweep_small_m.py): on small weight matrices the weight-streaming skinny kernel wins up
         // to M = 48 (K = N = 4096: 8.5-11.4 vs 11.4-12.6 us); on large ones (N*K >= 24 MiB) the split-K tile
@@ -246,6 +258,8 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     case FP8MI_KERNEL_GEMM_128x64:
     case FP8MI_KERNEL_GEMM_256:
     case FP8MI_KERNEL_GEMM_64x128:
+    case FP8MI_KERNEL_GEMM_64x64:
+    case FP8MI_KERNEL_GEMM_32x64:
         if (K <= 0 || !fp8mi_gemm_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "MFMA gemm kernel needs K > 0, K %% 16 == 0 and 16-byte aligned rows");
         return hip_result(fp8mi_launch_gemm(p, kernel, s), "gemm");
     case FP8MI_KERNEL_GEMM_256W:
@@ -265,7 +279,7 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
 #ifdef FP8MI_DIAG  // diagnostic library only: schedule variants of the ring kernel (7..13, 30..37), the producer / consumer kernel
                    // (15..24) and its timing-only ablations (201..207)
         if (K > 0 && fp8mi_gemm_supported(p)) {
-            if ((kernel >= 7 && kernel <= 13) || (kernel >= 30 && kernel <= 39) || (kernel >= 120 && kernel <= 149)) return hip_result(fp8mi_launch_gemm(p, kernel, s), "gemm-variant");
+            if ((kernel >= 7 && kernel <= 13) || (kernel >= 30 && kernel <= 39) || (kernel >= 120 && kernel <= 169)) return hip_result(fp8mi_launch_gemm(p, kernel, s), "gemm-variant");
             if ((kernel >= 15 && kernel <= 29) || (kernel >= 200 && kernel < 220)) return hip_result(fp8mi_launch_gemm_pc(p, kernel, s), "gemm-pc");
         }
 #endif

@@ -648,6 +648,11 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     case FP8MI_KERNEL_GEMM_128x64: return launch<128, 64, 32, 32, 3, 1, 1, 2, 4>(p, s);  // 3 x 48 KiB ring, 2 K-steps per stage, L2 prefetch one stage beyond the ring (C3 16.0 -> 15.3 us)
     case FP8MI_KERNEL_GEMM_256: return launch<256, 256, 128, 64, 2, 2, 0, 1, 4>(p, s);   // 2 x 64 KiB ring, staggered wave groups
     case FP8MI_KERNEL_GEMM_64x128: return launch<64, 128, 32, 32, 3, 1, 0, 2, 4>(p, s);  // 3 x 48 KiB ring, for M <= 64
+    // small-batch tiles (round 3, tools/sweep_decode.py, profiles/r03_decode_tiles.txt): against a deep K a 64x128 tile x 8 K slices leaves 32 KiB
+    // partials and a last arriver that re-reads 256 KiB; 64x64 x 4 slices (16 KiB partials) and, for M <= 32, 32x64 tiles (half the x traffic)
+    // took 13-30 % less time on every shape of the sweep (K=14336 N=4096: M=32 17.2 -> 13.2 us, M=64 17.2 -> 14.9 us)
+    case FP8MI_KERNEL_GEMM_64x64: return launch<64, 64, 16, 32, 4, 1, 0, 2, 4>(p, s);    // 8 waves of 16x32, 4 x 32 KiB ring, waves 0-3 load
+    case FP8MI_KERNEL_GEMM_32x64: return launch<32, 64, 16, 32, 4, 1, 0, 2, 4>(p, s);    // 4 waves of 16x32, 4 x 24 KiB ring
     case FP8MI_KERNEL_GEMM_256W: return fp8mi_launch_gemm256(p, 0, s);                   // (only chosen above when fp8mi_gemm256_supported)
     case FP8MI_KERNEL_GEMM_256x128W: return fp8mi_launch_gemm256(p, 1000, s);
 #ifdef FP8MI_DIAG  // schedule variants kept for A/B timing (diagnostic library only; same results): tools/ab_kernels.py
@@ -673,6 +678,14 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     case 136: return launch<128, 128, 64, 32, 4, 0, 0, 1, 4>(p, s);            //   4 x 32 KiB, stage DMA first
     case 140: return launch<128, 64, 32, 32, 3, 1, 9, 2, 4>(p, s);             // 128x64 as shipped + A-panel prefetch by one more wave
     case 141: return launch<128, 64, 32, 32, 3, 1, 10, 2, 4>(p, s);            //   ... both two stages ahead
+    case 150: return launch<64, 64, 32, 32, 3, 1, 0, 2, 4>(p, s);              // 64x64 tiles, 4 waves, 3 x 32 KiB ring (decode regime: M <= 64 with a 4-way K split instead of 64x128 x 8)
+    case 151: return launch<64, 64, 32, 32, 4, 1, 0, 2, 4>(p, s);              //   4 x 32 KiB
+    case 152: return launch<64, 64, 16, 32, 4, 1, 0, 2, 4>(p, s);              //   8 waves
+    case 153: return launch<32, 128, 16, 32, 3, 1, 0, 2, 4>(p, s);             // 32x128, 8 waves of 16x32, 3 x 40 KiB (M <= 32)
+    case 154: return launch<32, 64, 16, 32, 4, 1, 0, 2, 4>(p, s);              // 32x64, 4 waves, 4 x 24 KiB
+    case 155: return launch<16, 128, 16, 32, 4, 1, 0, 2, 2>(p, s);             // 16x128, 4 waves (2 loading), 4 x 36 KiB (M <= 16)
+    case 156: return launch<64, 64, 16, 32, 3, 1, 0, 2, 4>(p, s);              // 64x64, 8 waves, 3 x 32 KiB
+    case 157: return launch<64, 64, 16, 32, 2, 1, 0, 2, 4>(p, s);              // 64x64, 8 waves, 2 x 32 KiB (two workgroups per CU)
     case 7: return launch<128, 64, 64, 32, 6>(p, s);                           // 128x64, 4 waves
     case 8: return launch<128, 128, 64, 64, 4>(p, s);                          // 128x128, 4 waves, 4-stage ring
     case 9: return launch<256, 128, 64, 64, 3, 0, 0, 1, 4>(p, s);              // 256x128, 8 waves (0-3 load), 3 x 48 KiB

@@ -41,6 +41,8 @@ KERNEL_GEMV_FP32 = 18
 KERNEL_GEMV_MX = 19
 KERNEL_GEMM_256W = 20
 KERNEL_GEMM_256x128W = 21
+KERNEL_GEMM_64x64 = 22
+KERNEL_GEMM_32x64 = 23
 WS_COUNTER_BYTES = 4096
 EPILOGUE_TRANSPOSED = 0x100  # OR into bias_dtype (include/fp8mi.h)
 

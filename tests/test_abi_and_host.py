@@ -270,8 +270,12 @@ def test_automatic_dispatch_table():
     assert pick(4, 4096, 4096) == L.KERNEL_GEMV_MX and pick(2, 4096, 14336) == L.KERNEL_GEMV_MX    # the reference's batch-4 shape
     assert pick(8, 14336, 4096) == L.KERNEL_GEMV_MX and pick(8, 4096, 4096) == L.KERNEL_SKINNY     # 5..8 rows: deep K only
     assert pick(6, 4096, 14336) == L.KERNEL_GEMM_128x64                                            # wide N fills the chip unsplit
-    assert pick(32, 4096, 4096) == L.KERNEL_SKINNY
-    assert pick(64, 14336, 4096) == L.KERNEL_GEMM_64x128 and pick(64, 14336, 4096, ws=0) == L.KERNEL_GEMM_128x64   # split-K needs the workspace
+    assert pick(32, 4096, 4096) == L.KERNEL_GEMM_32x64 and pick(32, 2048, 2048) == L.KERNEL_SKINNY   # small matrices stay on the skinny kernel
+    assert pick(32, 4096, 4096, ws=0) == L.KERNEL_SKINNY and pick(32, 4096, 4096, split=1) == L.KERNEL_SKINNY   # the small tiles live on the K split
+    assert pick(9, 14336, 4096) == L.KERNEL_GEMM_32x64 and pick(24, 12288, 3072) == L.KERNEL_GEMM_32x64       # the decode regime (round 3)
+    assert pick(64, 14336, 4096) == L.KERNEL_GEMM_64x64 and pick(64, 14336, 4096, ws=0) == L.KERNEL_GEMM_128x64   # split-K needs the workspace
+    assert pick(48, 4096, 14336) == L.KERNEL_GEMM_64x64 and pick(96, 4096, 4096) == L.KERNEL_GEMM_64x64
+    assert pick(96, 4096, 14336) == L.KERNEL_GEMM_128x64 and pick(128, 14336, 4096) == L.KERNEL_GEMM_128x64    # wide N / M > 96 against deep K: 128x64
     assert pick(512, 4096, 4096, out=L.F32) == L.KERNEL_GEMM_128x64                                # config C3
     assert pick(4096, 3072, 12288) == L.KERNEL_GEMM_256W and pick(8192, 8192, 8192) == L.KERNEL_GEMM_256W   # FLUX, 8192^3
     assert pick(4173, 3072, 12296) == L.KERNEL_GEMM_256W                                           # ragged M and N stay on it
