@@ -346,7 +346,7 @@ def _probe_lib():
         lib.probe_mfma_flops.restype = ctypes.c_double
         lib.probe_mfma_flops.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
         lib.probe_read.restype = ctypes.c_int
-        lib.probe_read.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_int, vp]
+        lib.probe_read.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, vp]
         _PROBE = lib
     return _PROBE
 
@@ -356,7 +356,8 @@ def measure_ceilings(dev, info):
       mfma_TFLOPs        fp8 MFMA (the GEMM's instruction) back to back from registers on weight-like bytes, every CU busy
       read_large_GBs     streaming read of a 2 GiB buffer (cold: larger than the 256 MiB Infinity Cache)
       read_56MiB_GBs     a 56 MiB buffer read once per launch, 6 rotating buffers (the size of config C2's weights):
-                         includes the launch ramp a 10 us kernel cannot amortise."""
+                         includes the launch ramp a 10 us kernel cannot amortise.
+    Both in the launch shape the round-3 sweep found fastest (tools/probes/read_sweep.hip)."""
     try:
         lib = _probe_lib()
         st = torch.cuda.current_stream(dev)
@@ -379,7 +380,9 @@ def measure_ceilings(dev, info):
         mfma = lib.probe_mfma_flops(blocks, waves, iters) / t / 1e12
         sink = torch.zeros(1, dtype=torch.int32, device=dev)
         big = torch.ones(2 << 30, dtype=torch.uint8, device=dev)
-        t = timed(lambda: lib.probe_read(big.data_ptr(), sink.data_ptr(), big.numel(), 4096, st.cuda_stream), 8)
+        # (grid, loads in flight per lane) = the fastest of the round-3 sweep per buffer size (profiles/r03_read_sweep.txt); round 2's single
+        # point (2048 / 4096 workgroups, 4 in flight) read 10-20 % below these
+        t = timed(lambda: lib.probe_read(big.data_ptr(), sink.data_ptr(), big.numel(), 256, 8, st.cuda_stream), 8)
         read_large = big.numel() / t / 1e9
         del big
         n56 = 56 << 20
@@ -387,7 +390,7 @@ def measure_ceilings(dev, info):
         it = [0]
 
         def rot():
-            lib.probe_read(bufs[it[0] % 6].data_ptr(), sink.data_ptr(), n56, 2048, st.cuda_stream)
+            lib.probe_read(bufs[it[0] % 6].data_ptr(), sink.data_ptr(), n56, 2048, 1, st.cuda_stream)
             it[0] += 1
         t = timed(rot, 600)
         read_small = n56 / t / 1e9

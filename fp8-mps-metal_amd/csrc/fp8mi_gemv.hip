@@ -43,9 +43,14 @@ FP8MI_DEVICE void decode16(const u32x4 &w, f32x2 (&f)[8])
     }
 }
 
-template <int STEPS, int RB, bool NT = true, int kWaves = 4, int ABL = 0, bool MFMA = false>
+// OCC > 0: at most OCC workgroups of this kernel per CU (an LDS allocation of 160 KiB / OCC does it): bounds the bytes the CU has in flight
+template <int STEPS, int RB, bool NT = true, int kWaves = 4, int ABL = 0, bool MFMA = false, int OCC = 0>
 __global__ __launch_bounds__(kWaves * 64) void gemv_kernel(MMParams p_in)
 {
+    if constexpr (OCC > 0) {
+        __shared__ int occ_pad[(160 * 1024 / OCC - 512) / 4];
+        if (p_in.debug == 0x7FFFFFFF) occ_pad[threadIdx.x] = 1;   // (never true: keeps the allocation)
+    }
     const MMParams p = pin_params(p_in);  // every kernel argument in one scalar-load clause (fp8mi_common.h)
     // epilogue scalars: fetched now, under the weight stream (loaded where they are used they were a dependent global load
     // between the reduction and the store)
@@ -219,7 +224,9 @@ __global__ __launch_bounds__(kWaves * 64) void gemv_kernel(MMParams p_in)
 // multiplied with the matching bytes of EVERY x row by one MFMA per row (the diagonal trick above; the matrix pipe has the
 // headroom: MX MFMAs per 2 KiB of W).  The skinny kernel (fragment-shaped loads, one workgroup per 16 rows of W) stays for
 // 9 <= M <= 64.
-template <int STEPS, int RB, int MX, int G, int kWaves = 4>
+// SWEEP: group g of workgroup b holds rows (g * gridDim + b) * RB ..: at any moment the workgroups in flight read ONE contiguous window of W that moves
+// through the matrix (the access pattern of the fastest streaming-read probe, tools/probes/read_sweep.hip) instead of gridDim separate spans
+template <int STEPS, int RB, int MX, int G, int kWaves = 4, bool SWEEP = false>
 __global__ __launch_bounds__(kWaves * 64) void gemv_mx_kernel(MMParams p_in)
 {
     // A workgroup owns G groups of RB consecutive rows of W and keeps its K-slices of all MX rows of x in registers across
@@ -240,6 +247,9 @@ __global__ __launch_bounds__(kWaves * 64) void gemv_mx_kernel(MMParams p_in)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t row0 = (int64_t)blockIdx.x * kRows;
+    auto rown = [&](int r) -> int64_t {   // global row of the workgroup's r-th row (r = g * RB + row in group)
+        return SWEEP ? ((int64_t)(r / RB) * gridDim.x + blockIdx.x) * RB + (r % RB) : row0 + r;
+    };
     const int64_t K = p.K;
     const uint8_t *__restrict__ X = p.A;
     const uint8_t *__restrict__ W = p.B;
@@ -268,7 +278,7 @@ __global__ __launch_bounds__(kWaves * 64) void gemv_mx_kernel(MMParams p_in)
         auto load_group = [&](int g, u32x4 (&w)[RB][STEPS]) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                const int64_t n = row0 + g * RB + r;
+                const int64_t n = rown(g * RB + r);
                 const uint8_t *wr = W + n * p.ldb;
 #pragma unroll
                 for (int i = 0; i < STEPS; ++i) {
@@ -334,7 +344,7 @@ __global__ __launch_bounds__(kWaves * 64) void gemv_mx_kernel(MMParams p_in)
     int dirty = 0;
     const int cm = threadIdx.x / kRows, cr = threadIdx.x % kRows;  // this thread's output cell (threads 0 .. MX*kRows-1)
     auto finish = [&](int m, int r, float sum) {
-        const int64_t n = row0 + r;
+        const int64_t n = rown(r);
         const float sa = p.sa_row ? p.scale_a[m] : sa0;
         const float sw = p.sb_row ? p.scale_b[n] : sw0;
         const float b = p.bias ? load_as_float(p.bias, p.transposed ? (int64_t)m : n, p.bias_dtype) : 0.0f;
@@ -350,7 +360,7 @@ __global__ __launch_bounds__(kWaves * 64) void gemv_mx_kernel(MMParams p_in)
             for (int j = 0; j < 16; ++j) sum += part[wv][cm][cr][j];
         dirty = (p.nan_zero && sum != sum) ? 1 : 0;
         dirty_cell[cm][cr] = dirty;
-        if (cm < M && row0 + cr < p.N && !dirty) finish(cm, cr, sum);
+        if (cm < M && rown(cr) < p.N && !dirty) finish(cm, cr, sum);
     }
     if (!__syncthreads_or(dirty)) return;
 
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(kWaves * 64) void gemv_mx_kernel(MMParams p_in)
     for (int m = 0; m < M; ++m)
         for (int r = 0; r < kRows; ++r) {
             if (!dirty_cell[m][r]) continue;  // block-uniform
-            const int64_t n = row0 + r;
+            const int64_t n = rown(r);
             if (n >= p.N) continue;
             const uint8_t *wr = W + n * p.ldb;
             const uint8_t *xm = X + (int64_t)m * p.lda;
@@ -378,18 +388,18 @@ __global__ __launch_bounds__(kWaves * 64) void gemv_mx_kernel(MMParams p_in)
         }
 }
 
-template <int STEPS, int RB, int MX, int G, int kWaves = 4>
+template <int STEPS, int RB, int MX, int G, int kWaves = 4, bool SWEEP = false>
 int launch_mx(const MMParams &p, hipStream_t s)
 {
     const int64_t grid = (p.N + RB * G - 1) / (RB * G);
-    return fp8mi_launch(gemv_mx_kernel<STEPS, RB, MX, G, kWaves>, dim3((unsigned)grid), dim3(kWaves * 64), s, p);
+    return fp8mi_launch(gemv_mx_kernel<STEPS, RB, MX, G, kWaves, SWEEP>, dim3((unsigned)grid), dim3(kWaves * 64), s, p);
 }
 
-template <int STEPS, int RB, bool NT = true, int kWaves = 4, int ABL = 0, bool MFMA = false>
+template <int STEPS, int RB, bool NT = true, int kWaves = 4, int ABL = 0, bool MFMA = false, int OCC = 0>
 int launch(const MMParams &p, hipStream_t s)
 {
     const int64_t grid = (p.N + RB - 1) / RB;
-    return fp8mi_launch(gemv_kernel<STEPS, RB, NT, kWaves, ABL, MFMA>, dim3((unsigned)grid), dim3(kWaves * 64), s, p);
+    return fp8mi_launch(gemv_kernel<STEPS, RB, NT, kWaves, ABL, MFMA, OCC>, dim3((unsigned)grid), dim3(kWaves * 64), s, p);
 }
 
 }  // namespace
@@ -473,6 +483,33 @@ int fp8mi_launch_gemv_variant(const MMParams &p, int id, hipStream_t s)
     case 62: return launch<2, 2, true, 4, 0, true>(p, s);
     case 63: return launch<4, 1, true, 4, 0, true>(p, s);
     case 64: return launch<1, 1, true, 4, 0, true>(p, s);
+    case 65: return launch<4, 2, true, 4, 0, true, 2>(p, s);   // <4,2> MFMA with at most 2 / 3 / 4 / 6 workgroups per CU
+    case 66: return launch<4, 2, true, 4, 0, true, 3>(p, s);
+    case 67: return launch<4, 2, true, 4, 0, true, 4>(p, s);
+    case 68: return launch<4, 2, true, 4, 0, true, 6>(p, s);
+    case 69: return launch<4, 1, true, 4, 0, true, 4>(p, s);   // <4,1> with at most 4 / 6 per CU
+    case 160: return launch<4, 1, true, 4, 0, true, 6>(p, s);
+    case 161: return launch<4, 4, true, 4, 0, true, 2>(p, s);
+    // M == 1 on the few-rows kernel's structure (x kept in registers across G groups of 2 rows, next group's loads under this group's MFMAs):
+    // x traffic from L2 = 1 / (2 G) of the W stream instead of 1 / 2
+    case 162: return launch_mx<4, 2, 1, 2>(p, s);
+    case 163: return launch_mx<4, 2, 1, 4>(p, s);
+    case 164: return launch_mx<4, 2, 1, 8>(p, s);
+    case 165: return launch_mx<4, 1, 1, 8>(p, s);
+    case 166: return launch_mx<4, 1, 1, 4>(p, s);
+    case 167: return launch_mx<4, 1, 1, 16>(p, s);
+    case 168: return launch_mx<2, 1, 1, 8>(p, s);     // K <= 8192
+    case 169: return launch_mx<2, 2, 1, 4>(p, s);
+    case 170: return launch_mx<2, 1, 1, 8, 8>(p, s);  // 8 waves x 2 steps: K <= 16384
+    case 171: return launch_mx<2, 2, 1, 4, 8>(p, s);
+    case 174: return launch_mx<4, 1, 1, 4, 4, true>(p, s);   // ... with the rows of a workgroup dealt out gridDim apart (one moving window)
+    case 175: return launch_mx<4, 1, 1, 8, 4, true>(p, s);
+    case 176: return launch_mx<4, 2, 1, 4, 4, true>(p, s);
+    case 177: return launch_mx<4, 2, 1, 2, 4, true>(p, s);
+    case 178: return launch_mx<4, 1, 1, 16, 4, true>(p, s);
+    case 179: return launch_mx<2, 2, 1, 4, 4, true>(p, s);   // K <= 8192
+    case 172: return launch_mx<1, 2, 1, 4>(p, s);     // K <= 4096
+    case 173: return launch_mx<1, 1, 1, 8>(p, s);
     default: return FP8MI_E_ENUM;
     }
 }
@@ -496,5 +533,11 @@ int fp8mi_launch_gemv(const MMParams &p, bool fp32_only, hipStream_t s)
         return launch<4, 2>(p, s);
     }
     if (steps <= 2) return launch<2, 2, true, 4, 0, true>(p, s);
+    // Round 3: deep K against a matrix of few rows (config C2) on the few-rows kernel's structure with ONE row of x - x stays in registers
+    // across 4 groups of 2 weight rows (x traffic from L2: 1/8 of the W stream instead of 1/2), the next group's loads go out under this
+    // group's MFMAs, and the groups of a workgroup are gridDim apart, so that the workgroups in flight read one contiguous window that moves
+    // through W (the walk of the fastest read kernel of tools/probes/read_sweep.hip).  C2: 10.82 against 11.12 us interleaved; K = N = 14336
+    // is 3-4 % slower that way (31.5 against 30.2) and stays on the plain form.
+    if (p.K <= 16384 && p.N <= 8192 && p.lda % 16 == 0) return launch_mx<4, 2, 1, 4, 4, true>(p, s);
     return launch<4, 2, true, 4, 0, true>(p, s);
 }
