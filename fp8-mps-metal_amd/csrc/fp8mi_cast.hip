@@ -17,6 +17,7 @@ constexpr int kBlock = 128;  // (128 / 256 / 512 / 1024 threads: 2^30 fp32 encod
 // workgroups the 2^30-element casts ran at 4.6-4.7 TB/s, with one-shot workgroups (262,144 of them for the fp32
 // encode) at 5.8 (encode) / 5.3 (dequant) TB/s - the dispatcher keeps the memory pipes fuller than a long loop does.
 constexpr int kMaxGrid = 1 << 22;
+constexpr int kDequantUnroll = 1;
 #ifndef FP8MI_CAST_UNROLL
 #define FP8MI_CAST_UNROLL 4  // 16-byte loads in flight per lane in the vector cast kernels
 #endif
@@ -122,7 +123,9 @@ __global__ __launch_bounds__(kBlock) void dequant_kernel(const uint8_t *__restri
     const int64_t n16 = count >> 4;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     const u32x4 *in4 = (const u32x4 *)in;
-    constexpr int kUn = FP8MI_CAST_UNROLL;
+    // ONE 16-byte piece per lane and pass (round 3, tools/probes/copy_sweep.hip: the memory instructions of this kernel alone - 16 B in, 2 x 16 B out
+    // per lane - move 6.07 TB/s as one pass per workgroup and 5.28 TB/s in round 2's shape of 4 pieces per lane on a quarter of the workgroups)
+    constexpr int kUn = kDequantUnroll;
     for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n16; i0 += stride * kUn) {
         u32x4 w[kUn];
 #pragma unroll
@@ -426,11 +429,13 @@ __global__ __launch_bounds__(kBlock) void encode_kernel(const void *__restrict__
                 for (int j = 0; j < kPer; ++j) f[u][j] = f[u][j] * ps;  // float32 multiply, as `inp * scale` (fp8_mps_native.py:179)
             }
             const uint32_t w0 = encode4<MODE>(f[u][0], f[u][1], f[u][2], f[u][3]);
+            // streaming stores: the bytes are written once and not read back here (copy_sweep.hip, this kernel's memory shape: 6.63 TB/s
+            // with nt stores against 6.33 with the default policy)
             if (kPer == 4) {
-                ((uint32_t *)out)[i] = w0;
+                __builtin_nontemporal_store(w0, (uint32_t *)out + i);
             } else {
                 const uint32_t w1 = encode4<MODE>(f[u][4], f[u][5], f[u][6], f[u][7]);
-                ((u32x2 *)out)[i] = u32x2{w0, w1};
+                __builtin_nontemporal_store(u32x2{w0, w1}, (u32x2 *)out + i);
             }
         }
     }
@@ -539,7 +544,7 @@ int fp8mi_launch_dequant(const uint8_t *in, void *out, const float *scale, int64
 {
     if (count == 0) return 0;
     const bool vec = aligned16(in) && aligned16(out);
-    const int grid = grid_for(vec ? (count >> 6) : count);  // vector kernel: 4 x 16 bytes per lane per pass
+    const int grid = grid_for(vec ? (count >> 4) / kDequantUnroll : count);  // vector kernel: 16 bytes per lane per pass
 #define FP8MI_DQ(OUT)                                                                                          \
     (vec ? fp8mi_launch(dequant_kernel<OUT>, dim3(grid), dim3(kBlock), s, in, out, scale, count)               \
          : fp8mi_launch(dequant_scalar_kernel<OUT>, dim3(grid), dim3(kBlock), s, in, out, scale, count))
