@@ -274,7 +274,7 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
 #ifdef FP8MI_DIAG
         if (kernel >= 80 && kernel <= 119 && fp8mi_gemm256_supported(p)) return hip_result(fp8mi_launch_gemm256(p, kernel - 80, s), "gemm256-variant");
         if (kernel >= 70 && kernel <= 73 && fp8mi_gemv_mx_supported(p)) return hip_result(fp8mi_launch_gemv_mx_variant(p, kernel, s), "gemv-mx-variant");
-        if (((kernel >= 40 && kernel <= 69) || (kernel >= 160 && kernel <= 179)) && fp8mi_gemv_supported(p)) return hip_result(fp8mi_launch_gemv_variant(p, kernel, s), "gemv-variant");
+        if (((kernel >= 40 && kernel <= 69) || (kernel >= 160 && kernel <= 189)) && fp8mi_gemv_supported(p)) return hip_result(fp8mi_launch_gemv_variant(p, kernel, s), "gemv-variant");
 #endif
 #ifdef FP8MI_DIAG  // diagnostic library only: schedule variants of the ring kernel (7..13, 30..37), the producer / consumer kernel
                    // (15..24) and its timing-only ablations (201..207)

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/fp8mi.h"
 
@@ -121,12 +122,24 @@ FP8MI_DEVICE float epilogue_value(float sum, float sa, float sb, bool has_bias, 
     return r;
 }
 
-// wave64 all-lanes sum
+// wave64 all-lanes sum.  Four DPP adds inside each row of 16 lanes (quad swaps, then the two mirrors: every lane of a row ends with
+// the row's sum), then the four row sums are read out as scalars.  (The generic `__shfl_xor` butterfly compiles to six DEPENDENT
+// ds_bpermute_b32 + s_waitcnt pairs - ~100 cycles each - per reduced value: 24 of them in series sat in the tail of every workgroup
+// of the 4-row vec-mat, ~1 us of config C1's 5.2 us.)
 FP8MI_DEVICE float wave_sum(float v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    auto dpp_add = [](float x, auto ctrl) {
+        const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, false);
+        return x + __builtin_bit_cast(float, y);
+    };
+    v = dpp_add(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1, 0, 3, 2]
+    v = dpp_add(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2, 3, 0, 1]
+    v = dpp_add(v, std::integral_constant<int, 0x141>{});   // row_half_mirror: lane i <- lane 7 - i of its half row
+    v = dpp_add(v, std::integral_constant<int, 0x140>{});   // row_mirror: lane i <- lane 15 - i of its row
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)),
+                r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // Per-dispatch timing hook (fp8mi_profile_begin / _end in the C ABI): while a profile is open on the calling thread

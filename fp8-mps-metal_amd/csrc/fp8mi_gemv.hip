@@ -480,6 +480,10 @@ int fp8mi_launch_gemv_variant(const MMParams &p, int id, hipStream_t s)
     case 59: return launch<1, 2, true, 4, 0, true>(p, s);
     case 60: return launch<1, 8, true, 4, 0, true>(p, s);
     case 61: return launch<1, 2>(p, s);
+    case 180: return launch<1, 1>(p, s);
+    case 181: return launch<1, 8>(p, s);
+    case 182: return launch<1, 2, true, 4, 0, false, 4>(p, s);   // <1,2> with at most 4 workgroups per CU
+    case 183: return launch<1, 4, false>(p, s);                  // default cache policy
     case 62: return launch<2, 2, true, 4, 0, true>(p, s);
     case 63: return launch<4, 1, true, 4, 0, true>(p, s);
     case 64: return launch<1, 1, true, 4, 0, true>(p, s);

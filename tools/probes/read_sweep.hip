@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -52,15 +53,16 @@ template <int U> kern_t pick(bool nt, bool span)
 
 int main(int argc, char **argv)
 {
-    const size_t small = 56u << 20, big = 2ull << 30;
-    const int nbuf = 6;
+    // argv[2] = size of the rotating buffers in MiB (default 56 = config C2's weights; 16 = config C1's), as many of them as exceed 320 MiB
+    const size_t small = (size_t)(argc > 2 ? atoi(argv[2]) : 56) << 20, big = 2ull << 30;
+    const int nbuf = (int)((320u << 20) / small) + 1;
     std::vector<void *> bufs(nbuf);
     for (auto &b : bufs) { hipMalloc(&b, small); hipMemset(b, 1, small); }
     void *bigbuf; hipMalloc(&bigbuf, big); hipMemset(bigbuf, 1, big);
     uint32_t *sink; hipMalloc(&sink, 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     struct Row { double gbs; int grid, U; bool nt, span; };
-    for (int which = 0; which < 2; ++which) {
+    for (int which = 0; which < (argc > 2 ? 1 : 2); ++which) {
         std::vector<Row> rows;
         const size_t bytes = which ? big : small;
         const int reps = which ? 12 : 360;
@@ -81,7 +83,8 @@ int main(int argc, char **argv)
                     }
         std::sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) { return a.gbs > b.gbs; });
         printf("== %s, back-to-back launches (events around %d launches: includes the launch boundary, as bench.py's step does) ==\n",
-               which ? "2 GiB buffer" : "56 MiB buffer read once per launch, 6 rotating", reps);
+               which ? "2 GiB buffer" : "rotating buffers (> 320 MiB in all), one read once per launch; MiB each =", reps);
+        if (!which) printf("   buffer size %zu MiB x %d buffers\n", small >> 20, nbuf);
         for (size_t i = 0; i < rows.size(); ++i)
             if (argc > 1 || i < 12 || i + 4 >= rows.size() || (rows[i].grid == 2048 && rows[i].U == 4 && rows[i].nt && !rows[i].span))
                 printf("  #%3zu  %7.1f GB/s  (%6.2f us per launch)  grid %6d  in flight %2d  %s  %s%s\n", i + 1, rows[i].gbs, bytes / rows[i].gbs / 1e3,
