@@ -77,6 +77,12 @@ int fp8mi_cu_count()
 static int choose_kernel(const MMParams &p)
 {
     if (fp8mi_gemv_supported(p)) return FP8MI_KERNEL_GEMV;
+    if (p.M >= 3 && p.M <= 8 && p.K <= 6144 && fp8mi_gemm_supported(p) && (p.N + 63) / 64 >= fp8mi_cu_count() / 2) {
+        // a few rows against a WIDE, shallow weight matrix: N alone fills the chip with unsplit 32x64 tiles, which stream W through the LDS-DMA ring
+        // while the few-rows kernel re-reads x per group of weight rows (round 3, tools/time_shape.py: M=4 K=4096 N=14336 12.1 against 14.6 us,
+        // M=8 11.9 against 14.8; M=4 K=3072 N=12288 8.8 against 12.1; M=8 K=4096 N=8192 9.8 against 13.0; M=2: equal, stays below)
+        return FP8MI_KERNEL_GEMM_32x64;
+    }
     if (fp8mi_gemv_mx_supported(p)) {
         // 2..8 rows of x on the vec-mat's weight-streaming structure (tools/check_gemv_mx.py time, MI355X): ahead of
         // the skinny and the split-K tile kernel for M <= 4 everywhere measured (K = N = 4096: 5.6 / 6.3 vs 7.8 us;
@@ -273,7 +279,7 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     default:
 #ifdef FP8MI_DIAG
         if (kernel >= 80 && kernel <= 119 && fp8mi_gemm256_supported(p)) return hip_result(fp8mi_launch_gemm256(p, kernel - 80, s), "gemm256-variant");
-        if (kernel >= 70 && kernel <= 73 && fp8mi_gemv_mx_supported(p)) return hip_result(fp8mi_launch_gemv_mx_variant(p, kernel, s), "gemv-mx-variant");
+        if (kernel >= 70 && kernel <= 77 && fp8mi_gemv_mx_supported(p)) return hip_result(fp8mi_launch_gemv_mx_variant(p, kernel, s), "gemv-mx-variant");
         if (((kernel >= 40 && kernel <= 69) || (kernel >= 160 && kernel <= 189)) && fp8mi_gemv_supported(p)) return hip_result(fp8mi_launch_gemv_variant(p, kernel, s), "gemv-variant");
 #endif
 #ifdef FP8MI_DIAG  // diagnostic library only: schedule variants of the ring kernel (7..13, 30..37), the producer / consumer kernel

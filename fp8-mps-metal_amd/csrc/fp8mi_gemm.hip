@@ -632,6 +632,13 @@ int fp8mi_choose_gemm_variant(const MMParams &p)
         else if (us256 <= us128 && us256 <= us64) variant = w256 ? FP8MI_KERNEL_GEMM_256W : FP8MI_KERNEL_GEMM_256;
         else if (us128 <= us64) variant = FP8MI_KERNEL_GEMM_128;
         else variant = FP8MI_KERNEL_GEMM_128x64;
+        // Round 3, M = 129 .. 512 (tools/sweep_decode.py with MS=160..512, profiles/r03_mid_m.txt): the fitted model is optimistic about a 128x128 grid
+        // that leaves the CUs one workgroup each (its two co-resident workgroups are what hides its prologue / epilogue) - up to two rounds of 128x64
+        // tiles are faster (M=512 K=N=8192: 51.7 against 59.5 us; M=256 K=4096 N=14336: 29.6 against 31.8) ...
+        if (variant == FP8MI_KERNEL_GEMM_128 && p.M <= 512 && t64 <= 2 * cus) variant = FP8MI_KERNEL_GEMM_128x64;
+        // ... and a shallow K on at most one round of 64x64 tiles beats half a round of 128x64 (M=256 K=N=4096: 11.6 against 14.3 us)
+        const double t6464 = (double)(((p.M + 63) / 64) * ((p.N + 63) / 64));
+        if (variant == FP8MI_KERNEL_GEMM_128x64 && p.M > 128 && p.K <= 4096 && t6464 <= cus && t64 <= cus / 2) variant = FP8MI_KERNEL_GEMM_64x64;
     }
     return variant;
 }

@@ -441,11 +441,14 @@ int fp8mi_launch_gemv_mx(const MMParams &p, hipStream_t s)
 int fp8mi_launch_gemv_mx_variant(const MMParams &p, int id, hipStream_t s)
 {
     const int64_t steps = (p.K + 4095) / 4096;
-    const int v = id - 70;
+    const bool sweep = id >= 74;   // 74..77: the same with the groups of a workgroup gridDim apart (one moving read window)
+    const int v = sweep ? id - 74 : id - 70;
     const int g = v == 0 ? 1 : (v == 1 ? 2 : (v == 2 ? 4 : 8));
 #define MXV(S, MXN)                                                             \
-    (g == 1 ? launch_mx<S, 2, MXN, 1>(p, s) : g == 2 ? launch_mx<S, 2, MXN, 2>(p, s) \
-     : g == 4 ? launch_mx<S, 2, MXN, 4>(p, s) : launch_mx<S, 2, MXN, 8>(p, s))
+    (sweep ? (g == 1 ? launch_mx<S, 2, MXN, 1, 4, true>(p, s) : g == 2 ? launch_mx<S, 2, MXN, 2, 4, true>(p, s) \
+              : g == 4 ? launch_mx<S, 2, MXN, 4, 4, true>(p, s) : launch_mx<S, 2, MXN, 8, 4, true>(p, s))        \
+           : (g == 1 ? launch_mx<S, 2, MXN, 1>(p, s) : g == 2 ? launch_mx<S, 2, MXN, 2>(p, s) \
+              : g == 4 ? launch_mx<S, 2, MXN, 4>(p, s) : launch_mx<S, 2, MXN, 8>(p, s)))
     if (p.M <= 2) return steps <= 1 ? MXV(1, 2) : steps <= 2 ? MXV(2, 2) : MXV(4, 2);
     if (p.M <= 4) return steps <= 1 ? MXV(1, 4) : steps <= 2 ? MXV(2, 4) : MXV(4, 4);
     if (steps <= 2) return steps <= 1 ? MXV(1, 8) : MXV(2, 8);

@@ -2,6 +2,7 @@
 // each variant repeats a block of 32 "items" and reports cycles per item.   hipcc --offload-arch=gfx950 -O3 tail_probe.hip -o tail_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #define REP32(x) x x x x x x x x x x x x x x x x x x x x x x x x x x x x x x x x
 #define READS "v_accvgpr_read_b32 v128, a0\n\tv_accvgpr_read_b32 v129, a1\n\tv_accvgpr_read_b32 v130, a2\n\tv_accvgpr_read_b32 v131, a3\n\tv_accvgpr_read_b32 v132, a4\n\tv_accvgpr_read_b32 v133, a5\n\tv_accvgpr_read_b32 v134, a6\n\tv_accvgpr_read_b32 v135, a7\n\t"
@@ -49,11 +50,12 @@ __global__ __launch_bounds__(256) void probe(unsigned long long *out, unsigned c
     if (lane == 0) out[blockIdx.x * 4 + wave] = c1 - c0;
 }
 
-int main()
+int main(int argc, char **argv)
 {
-    const int blocks = 256; const unsigned ldc_b = 12288 * 2;
+    const int blocks = argc > 1 ? atoi(argv[1]) : 256;   // workgroups (one per CU up to 256): fewer = fewer CUs storing at the same time
+    const unsigned ldc_b = 12288 * 2;
     unsigned long long *d; unsigned char *C;
-    hipMalloc(&d, blocks * 4 * 8); hipMalloc(&C, (size_t)blocks * 256 * ldc_b);
+    hipMalloc(&d, blocks * 4 * 8); hipMalloc(&C, (size_t)256 * 256 * ldc_b);
     std::vector<unsigned long long> h(blocks * 4);
     const char *names[] = {"8 accvgpr_read", "+ 4 permlane16_swap", "+ 8 pk_mul", "+ 4 cvt_pk", "+ store nt (scattered 16 rows x 64 B)", "store nt only", "store plain only",
                            "2 MFMA only", "2 MFMA + VALU item", "2 MFMA + VALU item + store", "4 swaps only", "8 pk_mul only", "4 cvt only"};

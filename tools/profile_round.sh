@@ -26,7 +26,7 @@ for w in ("gemm", "gemv", "gemv_sq", "flux", "mid", "skinny", "decode", "quantiz
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             # the workload's own kernel only (the synthetic-data generator also runs amax / encode kernels)
-            want = {"gemm": ("gemm_kernel",), "flux": ("gemm256_kernel", "gemm_kernel"), "mid": ("gemm256_kernel", "gemm_kernel"), "decode": ("gemm_kernel",), "gemv": ("gemv_kernel",),
+            want = {"gemm": ("gemm_kernel",), "flux": ("gemm256_kernel", "gemm_kernel"), "mid": ("gemm256_kernel", "gemm_kernel"), "decode": ("gemm_kernel",), "gemv": ("gemv_mx_kernel", "gemv_kernel"),
                     "gemv_sq": ("gemv_kernel",), "skinny": ("gemv_mx_kernel", "skinny_kernel"), "quantize": ("encode_kernel<0, 0, false>",),
                     "quantize_rne": ("encode_kernel<0, 1, false>",), "dequant": ("dequant_kernel",)}[w]
             if any(x in r["Kernel_Name"] for x in want):
@@ -42,7 +42,14 @@ for w in ("gemm", "gemv", "gemv_sq", "flux", "mid", "skinny", "decode", "quantiz
 import sys
 sys.path.insert(0, "$R")
 import bench   # the fingerprint of the kernel sources these numbers belong to (bench.py prints traffic only when it matches)
-json.dump({"source_sha": bench.source_fingerprint(), "traffic": out}, open(os.path.join(O, "pmc_traffic.json"), "w"), indent=1)
+import socket, subprocess
+try:
+    gpu = subprocess.run(["rocm-smi", "--showproductname"], capture_output=True, text=True, timeout=20).stdout
+    gpu = next((l.split(":")[-1].strip() for l in gpu.splitlines() if "Card Series" in l or "Card series" in l), "")
+except Exception:
+    gpu = ""
+json.dump({"source_sha": bench.source_fingerprint(), "box": {"host": socket.gethostname(), "gpu": gpu, "dev_kernarg": os.environ.get("HIP_FORCE_DEV_KERNARG", "")},
+           "traffic": out}, open(os.path.join(O, "pmc_traffic.json"), "w"), indent=1)
 open(os.path.join(O, "pmc_traffic_summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 PY

@@ -11,7 +11,7 @@ st = torch.cuda.current_stream().cuda_stream
 s1 = torch.full((1,), 0.01, device=dev)
 g = torch.Generator(device=dev).manual_seed(1)
 KN = [(14336, 4096), (8192, 8192), (4096, 14336), (12288, 3072), (4096, 4096), (7168, 7168)]
-MS = [9, 16, 32, 48, 64, 96, 128]
+MS = [int(x) for x in os.environ.get("MS", "9,16,32,48,64,96,128").split(",")]
 ids = [int(x) for x in sys.argv[1:]] or [0, L.KERNEL_GEMM_64x128, L.KERNEL_GEMM_128x64]
 for (K, N) in KN:
     nb = min(24, max(2, (320 << 20) // (N * K)))
