@@ -279,6 +279,7 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     default:
 #ifdef FP8MI_DIAG
         if (kernel >= 80 && kernel <= 119 && fp8mi_gemm256_supported(p)) return hip_result(fp8mi_launch_gemm256(p, kernel - 80, s), "gemm256-variant");
+        if (kernel >= 190 && kernel <= 199 && fp8mi_gemm256_supported(p)) return hip_result(fp8mi_launch_gemm256(p, 1000 + kernel - 190, s), "gemm256x128-variant");
         if (kernel >= 70 && kernel <= 77 && fp8mi_gemv_mx_supported(p)) return hip_result(fp8mi_launch_gemv_mx_variant(p, kernel, s), "gemv-mx-variant");
         if (((kernel >= 40 && kernel <= 69) || (kernel >= 160 && kernel <= 189)) && fp8mi_gemv_supported(p)) return hip_result(fp8mi_launch_gemv_variant(p, kernel, s), "gemv-variant");
 #endif

@@ -387,14 +387,17 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
         const TabRegs tabs = load_tables(p, fl_l, m0 + wm0, n0 + wn0, G::kCols, lane_l);   // in flight under the K loop, stored to the LDS behind it
         f32x32 acc4, acc5, acc6, acc7;   // fragment rows 4..7, pinned by the asm to a[128:255] (BN = 256) / a[64:127] (BN = 128: acc4, acc5)
         if (pass == 0) {
-            if constexpr (BN == 128) {
+            if constexpr (BN == 128 && V == 0) {
                 FP8MI_GEMM256_LOOP_N128();
             } else if constexpr (V == 0) {
                 FP8MI_GEMM256_LOOP();
             }
 #ifdef FP8MI_DIAG
-#define X(v) else if constexpr (V == v) { FP8MI_GEMM256_LOOP_V##v(); }
+#define X(v) else if constexpr (BN == 256 && V == v) { FP8MI_GEMM256_LOOP_V##v(); }
             FP8MI_GEMM256_VARIANTS
+#undef X
+#define X(v) else if constexpr (BN == 128 && V == v) { FP8MI_GEMM256_LOOP_N128_V##v(); }
+            FP8MI_GEMM256_NVARIANTS
 #undef X
 #endif
         } else {
@@ -468,7 +471,7 @@ extern "C" int fp8mi_debug_read_stamps256(unsigned long long *out, int n)
 // variant: 0 = the product loop on 256x256 tiles, 1000 = the same schedule on 256x128 tiles; others (diagnostic build) = schedule variants
 int fp8mi_launch_gemm256(const MMParams &p, int variant, hipStream_t s)
 {
-    const int bn = variant == 1000 ? 128 : 256;
+    const int bn = variant >= 1000 ? 128 : 256;
     const int64_t tm = (p.M + kBM - 1) / kBM, tn = (p.N + bn - 1) / bn;
     if (tm * tn > 0x7FFFFFFF) return FP8MI_E_UNSUPPORTED;
     const unsigned grid = (unsigned)(tm * tn);
@@ -478,6 +481,9 @@ int fp8mi_launch_gemm256(const MMParams &p, int variant, hipStream_t s)
 #ifdef FP8MI_DIAG
 #define X(v) case v: return fp8mi_launch(gemm256_kernel<v, 256>, dim3(grid), dim3(kThreads256), s, p, (int)tm, (int)tn, (int)grid);
     FP8MI_GEMM256_VARIANTS
+#undef X
+#define X(v) case 1000 + v: return fp8mi_launch(gemm256_kernel<v, 128>, dim3(grid), dim3(kThreads256), s, p, (int)tm, (int)tn, (int)grid);
+    FP8MI_GEMM256_NVARIANTS
 #undef X
 #endif
     default: return FP8MI_E_ENUM;

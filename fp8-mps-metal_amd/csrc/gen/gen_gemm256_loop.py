@@ -79,6 +79,10 @@ VARIANTS = {
     26: dict(wave_delay=32, dma_every=2),
     27: dict(wave_delay=24, dma_every=4),
 }
+# variants of the 256x128 form (diagnostic build; kernel ids 190 + n): its steps last half as long, so the same prefetch distance in stages is half the time
+NVARIANTS = {
+    1: dict(pf=3), 2: dict(pf=4), 3: dict(pf=6), 4: dict(pf=1), 5: dict(pf=0), 6: dict(dma_every_n=1), 7: dict(dma_every_n=1, pf=4), 8: dict(pf=8),
+}
 P = dict(PRODUCT)
 
 TN = 8   # W fragments per wave: 8 = 256x256 workgroup tile (wave 128x128), 4 = 256x128 (wave 128x64); set by the emitters below
@@ -189,7 +193,7 @@ def step(dma, reads):
         pre[LR].append(f"s_waitcnt lgkmcnt({2 * (TN - 1)})")
     else:
         pre[LR].append("s_waitcnt lgkmcnt(0)")
-    every = P["dma_every"] if TN == 8 else 2   # 12 instructions under 24 MFMAs on the 256x128 tile
+    every = P["dma_every"] if TN == 8 else P.get("dma_every_n", 2)   # 12 instructions under 24 MFMAs on the 256x128 tile
     pf_at = P["pf_at"] if TN == 8 else NM - 2
     if dma and not P["no_dma"]:
         for j, g in enumerate(dma_block("%[m0_c]", "%[k2]")):
@@ -522,4 +526,11 @@ if __name__ == "__main__":
         print(f"// variant {v}: {over}")
         emit(f"FP8MI_GEMM256_LOOP_V{v}", pipelined2() if P["schedule"] == 2 else pipelined(), False)
     print("#define FP8MI_GEMM256_VARIANTS " + " ".join(f"X({v})" for v in sorted(VARIANTS)))
+    TN = 4
+    for v, over in sorted(NVARIANTS.items()):
+        P.clear(); P.update(PRODUCT); P.update(over)
+        print(f"// 256x128 variant {v}: {over}")
+        emit(f"FP8MI_GEMM256_LOOP_N128_V{v}", pipelined(), False)
+    print("#define FP8MI_GEMM256_NVARIANTS " + " ".join(f"X({v})" for v in sorted(NVARIANTS)))
+    TN = 8
     print("#endif")
