@@ -269,10 +269,10 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
         if (K <= 0 || !fp8mi_gemm_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "MFMA gemm kernel needs K > 0, K %% 16 == 0 and 16-byte aligned rows");
         return hip_result(fp8mi_launch_gemm(p, kernel, s), "gemm");
     case FP8MI_KERNEL_GEMM_256W:
-        if (!fp8mi_gemm256_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "256x256 one-wave-per-SIMD kernel needs K %% 128 == 0, K >= 256, N a multiple of 16 bytes of output, 16-byte aligned rows, no split-K");
+        if (!fp8mi_gemm256_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "256x256 one-wave-per-SIMD kernel needs K >= 256 (> 256 with a K tail), N a multiple of 16 bytes of output, 16-byte aligned rows, no split-K");
         return hip_result(fp8mi_launch_gemm256(p, 0, s), "gemm256");
     case FP8MI_KERNEL_GEMM_256x128W:
-        if (!fp8mi_gemm256_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "256x128 one-wave-per-SIMD kernel needs K %% 128 == 0, K >= 256, N a multiple of 16 bytes of output, 16-byte aligned rows, no split-K");
+        if (!fp8mi_gemm256_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "256x128 one-wave-per-SIMD kernel needs K >= 256 (> 256 with a K tail), N a multiple of 16 bytes of output, 16-byte aligned rows, no split-K");
         return hip_result(fp8mi_launch_gemm256(p, 1000, s), "gemm256x128");
     case FP8MI_KERNEL_GENERIC:
         return hip_result(fp8mi_launch_generic(p, s), "generic");

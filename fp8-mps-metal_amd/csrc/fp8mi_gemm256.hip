@@ -295,7 +295,8 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
     const uint32_t sa = (uint32_t)(32 * p.lda), sb = (uint32_t)(32 * p.ldb);   // byte stride between a wave's consecutive row groups
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void *)smem;
     const uint32_t vscale = (uint32_t)kScaleOne;
-    const int nk = (int)(p.K / BK);  // >= 2 (host)
+    const int nk = (int)((p.K + BK - 1) / BK);  // >= 2 (host); >= 3 when the last K-step is partial
+    const int ktail = (int)(p.K % BK);          // bytes of a partial last K-step (a multiple of 16), 0 = none: its stage is staged with per-lane K masks
 
     STAMP256(1);
     // NaN bytes: the epilogue sums the accumulators it reads anyway; a NaN proves a NaN byte took part in this tile (finite
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
         const int row0 = wave * 8 + (lane_l >> 3); \
         const int chunk = (lane_l & 7) ^ (((wave & 1) * 4 + (lane_l >> 4)) & 7); \
         const uint32_t va0 = (uint32_t)(row0 * p.lda + chunk * 16), vb0 = (uint32_t)(row0 * p.ldb + chunk * 16); \
+        const uint32_t va0t = (ktail == 0 || chunk * 16 < ktail) ? va0 : kOOB, vb0t = (ktail == 0 || chunk * 16 < ktail) ? vb0 : kOOB; \
         const int fr = lane_l & 15, fg = lane_l >> 4; \
         const uint32_t off1 = (uint32_t)(fr * BK + ((fg ^ (fr >> 1)) << 4)), off2 = (uint32_t)(fr * BK + (((4 + fg) ^ (fr >> 1)) << 4)); \
         uint32_t alo_c = lds0 + wm0 * BK + off1, ahi_c = lds0 + wm0 * BK + off2; \
@@ -451,12 +453,13 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
 
 }  // namespace
 
-// any M and N (ragged last tiles; N a multiple of the 16-byte store: 4 fp32 / 8 half columns), whole K-steps (at least two), 16-byte
-// aligned output rows, no split-K
+// any M and N (ragged last tiles; N a multiple of the 16-byte store: 4 fp32 / 8 half columns), K >= 256 (a multiple of 16; round 3: a partial last
+// K-step is staged with per-lane masks by the loop's peeled step), 16-byte aligned output rows, no split-K
 bool fp8mi_gemm256_supported(const MMParams &p)
 {
     const int esz = p.out_dtype == FP8MI_F32 ? 4 : 2;
-    return fp8mi_gemm_supported(p) && p.M < 0x7FFFFF00 && p.N < 0x7FFFFF00 && (p.N % (16 / esz)) == 0 && (p.K % BK) == 0 && p.K >= 2 * BK && p.split <= 1 &&
+    // (K: a multiple of 16 as for every tile kernel; whole K-steps need two of them, a partial last one three - the tail stage is staged by the peeled step)
+    return fp8mi_gemm_supported(p) && p.M < 0x7FFFFF00 && p.N < 0x7FFFFF00 && (p.N % (16 / esz)) == 0 && ((p.K % BK) == 0 ? p.K >= 2 * BK : p.K > 2 * BK) && p.split <= 1 &&
            ((p.ldc * esz) % 16) == 0 && (((uintptr_t)p.C) % 16) == 0 && ((p.M + kBM - 1) / kBM) * ((p.N + 127) / 128) <= 0x7FFFFFFF &&
            p.ldc * esz * 128 < 0x7FFF0000;   // the epilogue addresses a wave tile (128 rows) with 32-bit offsets
 }

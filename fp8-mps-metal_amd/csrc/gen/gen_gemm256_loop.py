@@ -111,17 +111,19 @@ def rdX(tm, which):
     return rd(XF(tm), tm, f"%[alo_{which}]", f"%[ahi_{which}]")
 
 
-def dma_block(slot_m0, kreg, first=True):
+def dma_block(slot_m0, kreg, first=True, tail=False):
     """16 DMA instructions of one stage as a list of 16 instruction groups.  The row part of the source offset travels in a
     VGPR (v118 = va0 / vb0 + jo x row-group stride) and only k in the scalar offset: the hardware range-checks the VGPR offset
-    against the descriptor's num_records, so the rows of a ragged last m-tile beyond M read as zeros without a mask."""
+    against the descriptor's num_records, so the rows of a ragged last m-tile beyond M read as zeros without a mask.
+    tail: the stage is the LAST one of a K that is not a multiple of 128 - the lanes whose 16-byte chunk lies beyond K start from an out-of-range
+    offset (va0t / vb0t: kOOB for those lanes, va0 / vb0 otherwise), so the chunk reads as zeros (+0.0 in e4m3) instead of the next row's bytes."""
     groups = []
     for j in range(8 + TN):   # 8 row groups of the A panel, TN of the B panel per wave
         g = []
         if j == 0:
-            g += [f"s_mov_b32 m0, {slot_m0}", f"s_mov_b32 %[t0], {kreg}", "v_mov_b32 v118, %[va0]"]
+            g += [f"s_mov_b32 m0, {slot_m0}", f"s_mov_b32 %[t0], {kreg}", "v_mov_b32 v118, " + ("%[va0t]" if tail else "%[va0]")]
         elif j == 8:
-            g += ["s_add_u32 m0, m0, 0x1000", "v_mov_b32 v118, %[vb0]"]
+            g += ["s_add_u32 m0, m0, 0x1000", "v_mov_b32 v118, " + ("%[vb0t]" if tail else "%[vb0]")]
         else:
             g += ["s_add_u32 m0, m0, 0x1000"]
         g += ["s_nop 0"]
@@ -171,7 +173,7 @@ def canonical_prologue_reads():
     return out
 
 
-def step(dma, reads):
+def step(dma, reads, tail=False):
     NM, LR = 8 * TN, 8 * (TN - 1)   # MFMAs per step, index of the first MFMA of the last row
     pre = [[] for _ in range(NM)]
     post = [[] for _ in range(NM)]
@@ -196,7 +198,7 @@ def step(dma, reads):
     every = P["dma_every"] if TN == 8 else P.get("dma_every_n", 2)   # 12 instructions under 24 MFMAs on the 256x128 tile
     pf_at = P["pf_at"] if TN == 8 else NM - 2
     if dma and not P["no_dma"]:
-        for j, g in enumerate(dma_block("%[m0_c]", "%[k2]")):
+        for j, g in enumerate(dma_block("%[m0_c]", "%[k2]", tail=tail)):
             post[min(NM - 1, P["dma_first"] - 1 + j * every)] += g
         if P["pf"] and not P["pf_stagger"]:
             post[pf_at] += pf_group()
@@ -403,9 +405,14 @@ def pipelined(fused=None):
     L += zero_acc()
     L += [f"s_waitcnt vmcnt({8 + TN + (1 if P['pf'] else 0)})", "s_barrier"]
     L += canonical_prologue_reads()
-    L += ["s_cmp_eq_u32 %[nloop], 0", "s_cbranch_scc1 2f", "1:"]
+    # nloop = nk - 2 steps stage two steps ahead; the LAST of them (it stages the last K-step: the K tail, if any) is peeled and takes the
+    # tail operands (equal to the plain ones when K is a multiple of 128).  (4 SALU instructions ahead of the loop: 16 bytes, the
+    # hand-written stream keeps its 8-byte phase)
+    L += ["s_cmp_eq_u32 %[nloop], 0", "s_cbranch_scc1 3f", "s_sub_u32 %[nloop], %[nloop], 1", "s_cmp_eq_u32 %[nloop], 0", "s_cbranch_scc1 2f", "s_nop 0", "1:"]
     L += step(True, True)
     L += ["s_sub_u32 %[nloop], %[nloop], 1", "s_cmp_lg_u32 %[nloop], 0", "s_cbranch_scc1 1b", "2:"]
+    L += step(True, True, tail=True)
+    L += ["3:"]
     L += step(False, True)
     if fused:
         # one statement, three tails (the output type is a launch-time switch; as three statements hipcc kept a private copy of
@@ -428,12 +435,12 @@ def scrub_reg(r):
             "v_not_b32 %[vt0], %[vt0]", f"v_and_b32 v{r}, v{r}, %[vt0]"]
 
 
-def scrub_step(dma):
+def scrub_step(dma, tail=False):
     L = ["s_waitcnt vmcnt(0)", "s_barrier"]
     L += canonical_prologue_reads()
     L += ["s_waitcnt lgkmcnt(0)", "s_barrier"]  # everyone has read the slot: it may be refilled
     if dma:
-        for g in dma_block("%[m0_c]", "%[k2]"):
+        for g in dma_block("%[m0_c]", "%[k2]", tail=tail):
             L += g
         L.append("s_add_u32 %[k2], %[k2], 0x80")
     for r in list(range(128, 128 + 8 * TN)) + list(range(192, 256)):
@@ -453,9 +460,11 @@ def scrubbed():
         L += g
     L.append("s_add_u32 %[k2], %[k2], 0x80")
     L += zero_acc()
-    L += ["s_cmp_eq_u32 %[nloop], 0", "s_cbranch_scc1 2f", "1:"]
+    L += ["s_cmp_eq_u32 %[nloop], 0", "s_cbranch_scc1 3f", "s_sub_u32 %[nloop], %[nloop], 1", "s_cmp_eq_u32 %[nloop], 0", "s_cbranch_scc1 2f", "1:"]
     L += scrub_step(True)
     L += ["s_sub_u32 %[nloop], %[nloop], 1", "s_cmp_lg_u32 %[nloop], 0", "s_cbranch_scc1 1b", "2:"]
+    L += scrub_step(True, tail=True)
+    L += ["3:"]
     L += scrub_step(False)
     L += scrub_step(False)
     L += ["s_nop 7", "s_nop 7", "s_nop 7", "s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]
@@ -477,7 +486,7 @@ def emit(name, lines, scrub, fused=False):
             '[k2] "+s"(k2)', '[m0_c] "+s"(m0_c)', '[m0_n] "+s"(m0_n)', '[nloop] "+s"(nloop)', '[t0] "=&s"(t0)', '[t1] "=&s"(t1)']
     if scrub:
         outs += ['[vt0] "=&v"(vt0)', '[vt1] "=&v"(vt1)']
-    ins = ['[va0] "v"(va0)', '[vb0] "v"(vb0)', '[vscale] "v"(vscale)', '[ra] "s"(ra)', '[rb] "s"(rb)', '[sa] "s"(sa)', '[sb] "s"(sb)',
+    ins = ['[va0] "v"(va0)', '[vb0] "v"(vb0)', '[va0t] "v"(va0t)', '[vb0t] "v"(vb0t)', '[vscale] "v"(vscale)', '[ra] "s"(ra)', '[rb] "s"(rb)', '[sa] "s"(sa)', '[sb] "s"(sb)',
            '[drow] "v"(drow)', '[dkey] "v"(dkey)', '[pfoff] "v"(pfoff)', '[rpf] "s"(rpf)', '[klast] "s"(klast)', '[wave] "s"(wave_s)']
     # m0 is written by the DMA groups (s_mov_b32 / s_add_u32 m0): declared, so that LLVM never keeps an M0 initialisation of its own live across the statement
     if fused:

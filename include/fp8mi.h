@@ -77,7 +77,7 @@ enum { FP8MI_KERNEL_AUTO = 0,
        FP8MI_KERNEL_GEMM_64x128 = 14, /* 64x128x128 tile (M <= 64, deep K)            */
        FP8MI_KERNEL_GEMV_FP32 = 18,  /* M == 1, IEEE fp32 accumulation at every K     */
        FP8MI_KERNEL_GEMV_MX = 19,    /* 2 <= M <= 8 on the vec-mat's weight-streaming structure */
-       FP8MI_KERNEL_GEMM_256W = 20, /* 256x256 tile, one wave per SIMD, hand-scheduled K loop: any M, N (a multiple of 4 fp32 / 8 half columns), K % 128 == 0, K >= 256 */
+       FP8MI_KERNEL_GEMM_256W = 20, /* 256x256 tile, one wave per SIMD, hand-scheduled K loop: any M, N (a multiple of 4 fp32 / 8 half columns), K >= 256 (K % 16 == 0; a partial last K-step since round 3) */
        FP8MI_KERNEL_GEMM_256x128W = 21, /* the same on 256x128 tiles (shapes that give 256x256 tiles less than a round) */
        FP8MI_KERNEL_GEMM_64x64 = 22,  /* 64x64x128 tile, 8 waves (33 <= M <= 64 against deep K, and up to M = 128 while the tile grid is small; with split-K) */
        FP8MI_KERNEL_GEMM_32x64 = 23 }; /* 32x64x128 tile, 4 waves (9 <= M <= 32: the decode regime; with split-K) */

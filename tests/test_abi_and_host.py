@@ -284,7 +284,7 @@ def test_automatic_dispatch_table():
     assert pick(1536, 3072, 4096) == L.KERNEL_GEMM_256x128W                                        # the 8-GPU shard, transposed
     assert pick(1024, 4096, 4096) == L.KERNEL_GEMM_128
     assert pick(16384, 1024, 8192) == L.KERNEL_GEMM_256W                                           # shallow K: per-tile fixed cost decides
-    assert pick(4096, 3088, 12288) == L.KERNEL_GEMM_256                                            # K tail: ring kernel
+    assert pick(4096, 3088, 12288) == L.KERNEL_GEMM_256W                                           # K tail: staged with per-lane masks since round 3
     assert pick(4096, 3072, 12292) in (L.KERNEL_GEMM_256, L.KERNEL_GEMM_128)                       # N not a multiple of 8 half columns: a ring kernel
     assert pick(5, 100, 7) == L.KERNEL_GENERIC                                                     # K % 16 != 0
     assert pick(512, 4096, 4096, lda=4100) == L.KERNEL_GENERIC                                     # rows not 16-byte aligned

@@ -1,0 +1,69 @@
+"""GPU (MI355X): the automatic dispatch against every forced kernel that accepts the shape, TIMED on the box the test
+runs on (per-dispatch events, median of 24 launches over rotating weight buffers).  The dispatch rules are constants fitted
+on other boxes (fp8mi_choose_kernel); boxes differ by ~10 %, so this pins AUTO's REGRET - time(AUTO) / time(best
+forced kernel) - with a generous bound instead of the choice itself: a rule that went stale (a kernel got faster, a new one
+appeared) fails here instead of silently costing 30 %.  Shapes: the BASELINE configs, the bench's secondaries and one
+point of every regime the rules distinguish."""
+import pytest
+import torch
+
+import fp8_mi355x_lib as L
+
+pytestmark = pytest.mark.gpu
+
+FORCED = [L.KERNEL_GEMV, L.KERNEL_GEMV_MX, L.KERNEL_SKINNY, L.KERNEL_GEMM_32x64, L.KERNEL_GEMM_64x64, L.KERNEL_GEMM_64x128,
+          L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_128, L.KERNEL_GEMM_256, L.KERNEL_GEMM_256W, L.KERNEL_GEMM_256x128W]
+SHAPES = [(1, 4096, 4096), (1, 14336, 4096), (4, 4096, 4096), (6, 4096, 14336), (16, 14336, 4096), (32, 4096, 4096), (64, 14336, 4096),
+          (96, 4096, 4096), (256, 4096, 4096), (512, 4096, 4096), (512, 8192, 8192), (2048, 4096, 4096), (4096, 3072, 1536),
+          (4096, 3072, 12288)]
+MAX_REGRET = 1.25
+
+
+def _median_us(lib, run, n):
+    for i in range(n // 2):
+        run(i)
+    torch.cuda.synchronize()
+    with L.kernel_timer(n) as kt:
+        for i in range(n):
+            run(i)
+    torch.cuda.synchronize()
+    ms = sorted(kt.ms)
+    return ms[len(ms) // 2] * 1e3
+
+
+@pytest.mark.parametrize("M,K,N", SHAPES)
+def test_auto_within_a_quarter_of_the_best_forced_kernel(native, cuda, M, K, N):
+    lib = L.load()
+    g = torch.Generator(device=cuda).manual_seed(M + K + N)
+    nb = min(12, max(2, (288 << 20) // (N * K)))
+    Bs = [torch.randint(0, 120, (N, K), dtype=torch.uint8, device=cuda, generator=g) for _ in range(nb)]
+    A = torch.randint(0, 120, (M, K), dtype=torch.uint8, device=cuda, generator=g)
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=cuda)
+    s1 = torch.full((1,), 0.01, device=cuda)
+    ws = native._workspace(cuda)
+    st = torch.cuda.current_stream(cuda).cuda_stream
+
+    def runner(kid):
+        def run(i):
+            return lib.fp8mi_scaled_mm_ws(A.data_ptr(), Bs[i % nb].data_ptr(), C.data_ptr(), s1.data_ptr(), s1.data_ptr(), None, None,
+                                          M, N, K, K, K, N, 0, 0, L.BF16, 0, L.NAN_ZERO, kid, 0, ws.data_ptr(), ws.numel(), st)
+        return run
+
+    n = 24
+    t_auto = _median_us(lib, runner(L.KERNEL_AUTO), n)
+    times = {}
+    for kid in FORCED:
+        run = runner(kid)
+        if run(0) != 0:   # the kernel's envelope does not take this shape
+            continue
+        torch.cuda.synchronize()
+        t = _median_us(lib, run, n)
+        if t < 8.0 * t_auto:   # (a kernel far outside its regime: not worth more launches)
+            times[kid] = t
+    torch.cuda.synchronize()
+    assert times, "no forced kernel accepted the shape"
+    best = min(times, key=times.get)
+    picked = lib.fp8mi_choose_kernel(M, N, K, K, K, N, L.BF16, 1, 0)
+    assert t_auto <= MAX_REGRET * times[best] + 0.5, (
+        f"M={M} K={K} N={N}: AUTO (kernel {picked}) {t_auto:.1f} us, best forced kernel {best} {times[best]:.1f} us; all: "
+        + ", ".join(f"{k}: {v:.1f}" for k, v in sorted(times.items())))

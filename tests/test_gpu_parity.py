@@ -573,7 +573,8 @@ def test_fused_epilogue(native, cuda, oracle, out_dtype, M):
 
 @pytest.mark.parametrize("M,K,N", [(256, 256, 256), (256, 384, 512), (512, 1024, 256), (768, 640, 1024), (256, 4096, 256),
                                    (300, 512, 256), (257, 384, 512), (129, 1024, 256), (1000, 640, 768), (1, 256, 256),
-                                   (256, 384, 264), (512, 512, 1000), (300, 640, 520), (64, 1024, 8)])
+                                   (256, 384, 264), (512, 512, 1000), (300, 640, 520), (64, 1024, 8),
+                                   (256, 272, 256), (300, 400, 264), (512, 1040, 256), (257, 3088, 520), (128, 368, 128)])   # round 3: K tails (K % 128 != 0, staged with per-lane masks)
 @pytest.mark.parametrize("wk", [L.KERNEL_GEMM_256W, L.KERNEL_GEMM_256x128W])
 def test_gemm256w_parity_and_bits_of_the_ring_kernel(native, cuda, oracle, M, K, N, wk):
     """The generated-assembly loop keeps the ring kernels' LDS image, fragment -> MFMA operand map and K order, so its
@@ -628,7 +629,7 @@ def test_gemm256w_random_shapes(native, cuda, oracle, wk):
     for _ in range(10):
         M = int(rng.integers(1, 1100))
         N = 8 * int(rng.integers(1, 140))
-        K = 128 * int(rng.integers(2, 12))
+        K = 128 * int(rng.integers(2, 12)) + (16 * int(rng.integers(1, 8)) if rng.integers(3) == 0 else 0)   # every third shape: a K tail
         A = clean_bytes(rng, (M, K))
         B = clean_bytes(rng, (N, K))
         sa = rng.uniform(0.005, 0.02, size=M).astype(np.float32) if rng.integers(2) else np.array([0.01], np.float32)
@@ -650,7 +651,7 @@ def test_gemm256w_envelope_dispatch_and_exactness(native, cuda, oracle):
     so a wrong register or LDS address in the generated loop cannot hide behind the hardware tolerance; a padded row
     stride (lda, ldb, ldc > the row length) goes through the descriptors and the epilogue untouched."""
     z = torch.zeros
-    for (M, K, N) in ((256, 256, 301), (256, 128, 256), (256, 272, 256)):
+    for (M, K, N) in ((256, 256, 301), (256, 128, 256), (256, 144, 256), (256, 200, 256)):   # (a K tail needs three K-steps: K > 256)
         with pytest.raises(RuntimeError):
             native.fp8_scaled_mm(z(M, K, dtype=torch.uint8, device=cuda), z(N, K, dtype=torch.uint8, device=cuda), torch.ones(1),
                                  torch.ones(1), kernel=L.KERNEL_GEMM_256W)
