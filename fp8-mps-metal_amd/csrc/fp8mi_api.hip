@@ -98,8 +98,10 @@ static int choose_kernel(const MMParams &p)
         // (14.3-14.9 against 17.2-17.4) and on to M = 128 while 128x64 tiles would leave half the CUs idle (K=N=4096 M=96: 9.5 against 13.2;
         // K=N=8192 M=96: 19.0 against 22.5) - except M > 96 against K > 8192, where 128x64 x split stays 3-6 % ahead.
         const int64_t cus = fp8mi_cu_count(), t64 = ((p.M + 127) / 128) * ((p.N + 63) / 64);
-        if (p.M <= 32) return FP8MI_KERNEL_GEMM_32x64;
-        if (p.M <= 64 && (double)p.N * (double)p.K <= 16.0 * 1048576.0) return FP8MI_KERNEL_GEMM_32x64;   // (K=N=4096, M=48-64: 8.3 against 9.4 us)
+        // ... and 32x32 tiles where K and N stay within 8192: twice the tiles = half the K slices (none at N = 8192), the partial exchange being what the
+        // regime pays for (K=N=8192 M=32: 14.7 against 18.0 us; K=N=4096: 7.2 against 8.1); against a deeper K their doubled x traffic loses (K=12288 N=3072: 12.3 against 11.6)
+        if (p.M <= 32) return (p.N <= 8192 && p.K <= 8192) ? FP8MI_KERNEL_GEMM_32x32 : FP8MI_KERNEL_GEMM_32x64;
+        if (p.M <= 64 && (double)p.N * (double)p.K <= 16.0 * 1048576.0) return FP8MI_KERNEL_GEMM_32x32;   // (K=N=4096, M=48-64: 7.6 against 9.4 us on 64x64)
         if (p.M <= 64) return FP8MI_KERNEL_GEMM_64x64;
         if (t64 <= cus / 2 && !(p.M > 96 && p.K > 8192)) return FP8MI_KERNEL_GEMM_64x64;
     }
@@ -266,6 +268,7 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     case FP8MI_KERNEL_GEMM_64x128:
     case FP8MI_KERNEL_GEMM_64x64:
     case FP8MI_KERNEL_GEMM_32x64:
+    case FP8MI_KERNEL_GEMM_32x32:
         if (K <= 0 || !fp8mi_gemm_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "MFMA gemm kernel needs K > 0, K %% 16 == 0 and 16-byte aligned rows");
         return hip_result(fp8mi_launch_gemm(p, kernel, s), "gemm");
     case FP8MI_KERNEL_GEMM_256W:

@@ -660,6 +660,7 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     // took 13-30 % less time on every shape of the sweep (K=14336 N=4096: M=32 17.2 -> 13.2 us, M=64 17.2 -> 14.9 us)
     case FP8MI_KERNEL_GEMM_64x64: return launch<64, 64, 16, 32, 4, 1, 0, 2, 4>(p, s);    // 8 waves of 16x32, 4 x 32 KiB ring, waves 0-3 load
     case FP8MI_KERNEL_GEMM_32x64: return launch<32, 64, 16, 32, 4, 1, 0, 2, 4>(p, s);    // 4 waves of 16x32, 4 x 24 KiB ring
+    case FP8MI_KERNEL_GEMM_32x32: return launch<32, 32, 16, 32, 4, 1, 0, 2, 2>(p, s);    // 2 waves of 16x32, 4 x 16 KiB ring: N / 32 tiles need half the K slices (K = N = 8192, M = 32: 14.7 against 18.0 us)
     case FP8MI_KERNEL_GEMM_256W: return fp8mi_launch_gemm256(p, 0, s);                   // (only chosen above when fp8mi_gemm256_supported)
     case FP8MI_KERNEL_GEMM_256x128W: return fp8mi_launch_gemm256(p, 1000, s);
 #ifdef FP8MI_DIAG  // schedule variants kept for A/B timing (diagnostic library only; same results): tools/ab_kernels.py
@@ -693,6 +694,8 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     case 155: return launch<16, 128, 16, 32, 4, 1, 0, 2, 2>(p, s);             // 16x128, 4 waves (2 loading), 4 x 36 KiB (M <= 16)
     case 156: return launch<64, 64, 16, 32, 3, 1, 0, 2, 4>(p, s);              // 64x64, 8 waves, 3 x 32 KiB
     case 157: return launch<64, 64, 16, 32, 2, 1, 0, 2, 4>(p, s);              // 64x64, 8 waves, 2 x 32 KiB (two workgroups per CU)
+    case 158: return launch<64, 32, 16, 32, 4, 1, 0, 2, 4>(p, s);              // 64x32, 4 waves, 4 x 24 KiB (more tiles -> fewer K slices, smaller partials)
+    case 159: return launch<32, 32, 16, 32, 4, 1, 0, 2, 2>(p, s);              // 32x32, 2 waves, 4 x 16 KiB
     case 7: return launch<128, 64, 64, 32, 6>(p, s);                           // 128x64, 4 waves
     case 8: return launch<128, 128, 64, 64, 4>(p, s);                          // 128x128, 4 waves, 4-stage ring
     case 9: return launch<256, 128, 64, 64, 3, 0, 0, 1, 4>(p, s);              // 256x128, 8 waves (0-3 load), 3 x 48 KiB

@@ -80,7 +80,8 @@ enum { FP8MI_KERNEL_AUTO = 0,
        FP8MI_KERNEL_GEMM_256W = 20, /* 256x256 tile, one wave per SIMD, hand-scheduled K loop: any M, N (a multiple of 4 fp32 / 8 half columns), K >= 256 (K % 16 == 0; a partial last K-step since round 3) */
        FP8MI_KERNEL_GEMM_256x128W = 21, /* the same on 256x128 tiles (shapes that give 256x256 tiles less than a round) */
        FP8MI_KERNEL_GEMM_64x64 = 22,  /* 64x64x128 tile, 8 waves (33 <= M <= 64 against deep K, and up to M = 128 while the tile grid is small; with split-K) */
-       FP8MI_KERNEL_GEMM_32x64 = 23 }; /* 32x64x128 tile, 4 waves (9 <= M <= 32: the decode regime; with split-K) */
+       FP8MI_KERNEL_GEMM_32x64 = 23,  /* 32x64x128 tile, 4 waves (9 <= M <= 32: the decode regime; with split-K) */
+       FP8MI_KERNEL_GEMM_32x32 = 24 }; /* 32x32x128 tile, 2 waves (M <= 32 against K, N <= 8192: N / 32 tiles fill the chip with fewer K slices) */
 /* Other ids exist only in the diagnostic build of the library (libfp8mi_diag.so:
  * schedule variants, the producer/consumer kernel and its ablations, kept for
  * A/B timing - tools/README.md); the product library rejects them. */

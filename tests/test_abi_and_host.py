@@ -271,7 +271,8 @@ def test_automatic_dispatch_table():
     assert pick(8, 14336, 4096) == L.KERNEL_GEMV_MX and pick(8, 4096, 4096) == L.KERNEL_SKINNY     # 5..8 rows: deep K only
     assert pick(6, 4096, 14336) == L.KERNEL_GEMM_32x64 and pick(4, 3072, 12288, ws=0) == L.KERNEL_GEMM_32x64   # wide shallow N fills the chip with unsplit 32x64 tiles
     assert pick(6, 8192, 8192) == L.KERNEL_GEMV_MX                                                 # ... deep K stays on the few-rows kernel
-    assert pick(32, 4096, 4096) == L.KERNEL_GEMM_32x64 and pick(32, 2048, 2048) == L.KERNEL_SKINNY   # small matrices stay on the skinny kernel
+    assert pick(32, 4096, 4096) == L.KERNEL_GEMM_32x32 and pick(32, 2048, 2048) == L.KERNEL_SKINNY   # small matrices stay on the skinny kernel
+    assert pick(16, 8192, 8192) == L.KERNEL_GEMM_32x32 and pick(64, 4096, 4096) == L.KERNEL_GEMM_32x32   # K, N <= 8192: more tiles, fewer K slices
     assert pick(32, 4096, 4096, ws=0) == L.KERNEL_SKINNY and pick(32, 4096, 4096, split=1) == L.KERNEL_SKINNY   # the small tiles live on the K split
     assert pick(9, 14336, 4096) == L.KERNEL_GEMM_32x64 and pick(24, 12288, 3072) == L.KERNEL_GEMM_32x64       # the decode regime (round 3)
     assert pick(64, 14336, 4096) == L.KERNEL_GEMM_64x64 and pick(64, 14336, 4096, ws=0) == L.KERNEL_GEMM_128x64   # split-K needs the workspace

@@ -35,7 +35,7 @@ import fp8_mi355x_lib as L  # noqa: E402
 
 # every LDS-tiled MFMA kernel of the product library (the schedule variants and the producer/consumer kernel live in the
 # diagnostic library only: tools/check_kernel.py checks those against the oracle)
-TILE_KERNELS = [L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256, L.KERNEL_GEMM_64x128, L.KERNEL_GEMM_64x64, L.KERNEL_GEMM_32x64]
+TILE_KERNELS = [L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256, L.KERNEL_GEMM_64x128, L.KERNEL_GEMM_64x64, L.KERNEL_GEMM_32x64, L.KERNEL_GEMM_32x32]
 
 
 def dev(x, cuda, dtype=None):
@@ -731,6 +731,7 @@ def _counters_zero(native, cuda):
     (300, 2048, 300, L.KERNEL_GEMM_128, 2), (512, 1024, 512, L.KERNEL_GEMM_256, 2),
     (64, 14336, 512, L.KERNEL_GEMM_64x64, 0), (50, 3584, 200, L.KERNEL_GEMM_64x64, 4), (96, 4096, 320, L.KERNEL_GEMM_64x64, 7),   # round 3: the decode regime's tiles
     (32, 14336, 512, L.KERNEL_GEMM_32x64, 0), (9, 2992, 130, L.KERNEL_GEMM_32x64, 3), (40, 8192, 192, L.KERNEL_GEMM_32x64, 16),
+    (32, 8192, 512, L.KERNEL_GEMM_32x32, 0), (20, 2992, 100, L.KERNEL_GEMM_32x32, 5), (70, 4096, 96, L.KERNEL_GEMM_32x32, 2), (16, 8192, 8192, L.KERNEL_AUTO, 0),
     (24, 12288, 3072, L.KERNEL_AUTO, 0), (64, 4096, 4096, L.KERNEL_AUTO, 0), (96, 4096, 4096, L.KERNEL_AUTO, 0),                   # ... as AUTO picks them
     (16, 8192, 4096, L.KERNEL_AUTO, 0),            # M <= 32 with a large weight matrix: auto leaves the skinny kernel
     (33, 14336, 512, L.KERNEL_AUTO, 0)])
