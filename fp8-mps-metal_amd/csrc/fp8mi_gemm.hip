@@ -694,6 +694,9 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     case 155: return launch<16, 128, 16, 32, 4, 1, 0, 2, 2>(p, s);             // 16x128, 4 waves (2 loading), 4 x 36 KiB (M <= 16)
     case 156: return launch<64, 64, 16, 32, 3, 1, 0, 2, 4>(p, s);              // 64x64, 8 waves, 3 x 32 KiB
     case 157: return launch<64, 64, 16, 32, 2, 1, 0, 2, 4>(p, s);              // 64x64, 8 waves, 2 x 32 KiB (two workgroups per CU)
+    case 126: return launch<64, 16, 16, 16, 4, 1, 0, 2, 2>(p, s);              // 64x16, 4 waves (2 loading), 4 x 20 KiB: N / 16 tiles fill the chip at N = 4096 with NO K split (fp32 out only: timing experiment)
+    case 127: return launch<64, 16, 16, 16, 6, 1, 0, 2, 2>(p, s);              //   6 x 20 KiB
+    case 128: return launch<32, 16, 16, 16, 6, 1, 0, 2, 2>(p, s);              // 32x16, 2 waves
     case 158: return launch<64, 32, 16, 32, 4, 1, 0, 2, 4>(p, s);              // 64x32, 4 waves, 4 x 24 KiB (more tiles -> fewer K slices, smaller partials)
     case 159: return launch<32, 32, 16, 32, 4, 1, 0, 2, 2>(p, s);              // 32x32, 2 waves, 4 x 16 KiB
     case 7: return launch<128, 64, 64, 32, 6>(p, s);                           // 128x64, 4 waves

@@ -131,48 +131,56 @@ FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8
     // (num_records = the wave tile's valid rows: stores to rows of a ragged last m-tile beyond M are out of range and dropped)
     __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)((uint8_t *)p.C + (m_wave * ldc + n_wave) * kEsz), 0,
                                                                   (int)((int64_t)rows_ok * ldc * kEsz), 0x00020000);
-    constexpr int kNt = 2;                         // aux: streaming (nt) store - C is written once and not re-read here
+#ifndef FP8MI_EPI_AUX
+#define FP8MI_EPI_AUX 2
+#endif
+    constexpr int kNt = FP8MI_EPI_AUX;             // aux: streaming (nt) store - C is written once and not re-read here (0 = default policy: A/B builds only)
     const uint32_t ldc_b = (uint32_t)(ldc * kEsz);
     const bool has_sr = (flags & kFSr) != 0;        // uniform: the multiplication is skipped as a block when there is none
     const float sa_u = tab[0], sb_u = tab[128];   // per-tensor: every entry of the table is the scale
     f32x4 nan_sum = {0.0f, 0.0f, 0.0f, 0.0f};
-    // two batches per trip where registers allow: the LDS reads of the second are scheduled above the arithmetic of the first
-    constexpr int kUnroll = (TABLES || BIAS) ? 1 : 2;
-#pragma unroll kUnroll
-    for (int it0 = 0; it0 < kIters; it0 += kBatch) {
+    // One wave per SIMD: nothing but this wave's own instruction order hides the LDS latency.  Round 3: the batches are software-pipelined by
+    // hand - the LDS reads of batch t + 1 are issued (and fenced) ahead of the arithmetic and the stores of batch t (as a plain loop hipcc put
+    // every trip's reads behind the previous trip's stores: ~200 cycles of exposed latency per trip; with all of an epilogue's stores dropped
+    // FLUX only gets 2 % faster, so the epilogue's 11.4 k cycles per tile are its own instruction stream, not the store traffic).
+    struct Batch {
         f32x4 q0[kBatch], q1[kBatch], sb0[kBatch], sb1[kBatch], bn0[kBatch], bn1[kBatch];
         float sa[kBatch], bm[kBatch];
+    };
+    auto load = [&](int it0, Batch &B) {
 #pragma unroll
         for (int b = 0; b < kBatch; ++b) {
             const int rr = (it0 + b) * kRpi + rsub, r = rr & 15;   // row inside the half: fragment row rr >> 4, row r
             lds_cu8 *src = dump + (rr >> 4) * kDumpRow + r * (COLS * 4) + pp * 32;
             const int swap = (r & 1) * 16;                      // odd rows hold the pair's chunks exchanged: undo it in the address
-            q0[b] = *(lds_cf32x4 *)(src + swap);
-            q1[b] = *(lds_cf32x4 *)(src + (16 - swap));
+            B.q0[b] = *(lds_cf32x4 *)(src + swap);
+            B.q1[b] = *(lds_cf32x4 *)(src + (16 - swap));
             const int col = ((pp ^ (r >> 1)) & (kLpr - 1)) * 8, row = half * 64 + rr;
             if (TABLES) {
-                sa[b] = tab[row];
-                sb0[b] = *(lds_cf32x4 *)(tab + 128 + col);
-                sb1[b] = *(lds_cf32x4 *)(tab + 128 + col + 4);
+                B.sa[b] = tab[row];
+                B.sb0[b] = *(lds_cf32x4 *)(tab + 128 + col);
+                B.sb1[b] = *(lds_cf32x4 *)(tab + 128 + col + 4);
             }
             if (BIAS && !TRANSPOSED) {
-                bn0[b] = *(lds_cf32x4 *)(tab + 256 + col);
-                bn1[b] = *(lds_cf32x4 *)(tab + 256 + col + 4);
+                B.bn0[b] = *(lds_cf32x4 *)(tab + 256 + col);
+                B.bn1[b] = *(lds_cf32x4 *)(tab + 256 + col + 4);
             }
-            if (BIAS && TRANSPOSED) bm[b] = tab[384 + row];
+            if (BIAS && TRANSPOSED) B.bm[b] = tab[384 + row];
         }
+    };
+    auto process = [&](int it0, const Batch &B) {
         float v[kBatch][8];
 #pragma unroll
         for (int b = 0; b < kBatch; ++b) {
-            nan_sum += q0[b] + q1[b];
-            const f32x4 lo = q0[b], hi = q1[b];
+            nan_sum += B.q0[b] + B.q1[b];
+            const f32x4 lo = B.q0[b], hi = B.q1[b];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float a = j < 4 ? lo[j & 3] : hi[j & 3];
-                const float s_a = TABLES ? sa[b] : sa_u;
-                const float s_b = TABLES ? (j < 4 ? sb0[b][j & 3] : sb1[b][j & 3]) : sb_u;
+                const float s_a = TABLES ? B.sa[b] : sa_u;
+                const float s_b = TABLES ? (j < 4 ? B.sb0[b][j & 3] : B.sb1[b][j & 3]) : sb_u;
                 float x = TRANSPOSED ? (a * s_b) * s_a : (a * s_a) * s_b;
-                if (BIAS) x = x + (TRANSPOSED ? bm[b] : (j < 4 ? bn0[b][j & 3] : bn1[b][j & 3]));
+                if (BIAS) x = x + (TRANSPOSED ? B.bm[b] : (j < 4 ? B.bn0[b][j & 3] : B.bn1[b][j & 3]));
                 v[b][j] = x;
             }
         }
@@ -208,6 +216,31 @@ FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{w[0], w[1], w[2], w[3]}, rc, off, 0, kNt);
             }
+        }
+    };
+    constexpr int kTrips = kIters / kBatch;
+    static_assert(kIters % kBatch == 0 && kTrips >= 1, "whole batches");
+    constexpr bool kPipe = !(TABLES || BIAS) && kTrips >= 2;   // (with tables / bias two batches in flight do not fit the ~118 registers the asm leaves)
+    if constexpr (kPipe) {
+        Batch A, Bq;
+        load(0, A);
+#pragma unroll
+        for (int t = 0; t < kTrips; t += 2) {
+            if (t + 1 < kTrips) load((t + 1) * kBatch, Bq);
+            __builtin_amdgcn_sched_barrier(0);   // the next batch's reads stay ABOVE this batch's arithmetic and stores
+            process(t * kBatch, A);
+            if (t + 1 < kTrips) {
+                if (t + 2 < kTrips) load((t + 2) * kBatch, A);
+                __builtin_amdgcn_sched_barrier(0);
+                process((t + 1) * kBatch, Bq);
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int t = 0; t < kTrips; ++t) {
+            Batch A;
+            load(t * kBatch, A);
+            process(t * kBatch, A);
         }
     }
     return nan_sum;
@@ -420,7 +453,10 @@ __global__ __launch_bounds__(kThreads256) void gemm256_kernel(MMParams p_in, int
         int64_t ldc_e = p.ldc;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e), "+s"(m_wave), "+s"(n_wave), "+s"(fl), "+s"(ldc_e));
         const int cols_ok = min(max((int)p.N - (int)n_wave, 0), G::kCols);   // ... and columns (a multiple of the store width: fp8mi_gemm256_supported)
-        const int rows_ok = min(max((int)p.M - (int)m_wave, 0), 128);   // valid rows of this wave's tile (ragged last m-tile)
+        int rows_ok = min(max((int)p.M - (int)m_wave, 0), 128);   // valid rows of this wave's tile (ragged last m-tile)
+#ifdef FP8MI_DIAG
+        if (p.debug & 8) rows_ok = 0;   // timing-only: every store of the epilogue falls outside its descriptor and is dropped (what the epilogue costs without its store traffic)
+#endif
         lds_cu8 *dump = (lds_cu8 *)(lds_void *)(smem + wave_e * kDumpWave);
         float *tabw = (float *)(smem + kTabBase + wave_e * kTabBytes);
         store_tables(fl, tabs, tabw, lane_e);
