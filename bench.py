@@ -253,9 +253,57 @@ class Workload:
             self.launch(i, s)
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner to STDOUT when a communicator is created (librccl, NCCL_DEBUG unset); the driver wants ONE JSON line there.
+    File-descriptor level, because the writer is a C library."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
+def capture_sharded(w, dev):
+    """The sharded step (per linear: `chunks` GEMM launches + `chunks` in-place all-gathers on a side stream) as ONE HIP graph: eagerly the host
+    needs ~80 us per linear for the launches, events and collectives (1-rank rehearsal: 197 us per FLUX linear against 120 us of kernel), which at
+    N = 8 - shard GEMMs of ~12 us per chunk - would be the critical path.  RCCL collectives capture into HIP graphs (tested with one rank:
+    tests/test_gpu_patch.py); every rank must take the same branch, so success is agreed on with an all-reduce before the graph is used."""
+    ok, graph = 1, None
+    try:
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            w.step(None)   # warm: communicator, the module's side stream and events, allocator
+            w.step(None)
+        cur.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            w.step(None)
+        graph.replay()
+        torch.cuda.synchronize(dev)
+    except Exception as e:   # capture not possible here: every rank falls back to eager steps
+        ok = 0
+        log(f"[bench] sharded step not captured ({e!r}); running it eagerly")
+    t = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return graph if int(t.item()) == 1 else None
+
+
 def time_steps(w, steps, warmup, use_graph, world, n_streams=1):
     dev = w.dev
     graph = None
+    if (use_graph and w.sharded and dist.is_initialized() and dist.get_backend() == "nccl"
+            and os.environ.get("FP8MI_BENCH_SHARDED_GRAPH", "1") == "1"):
+        graph = capture_sharded(w, dev)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 and not w.sharded else None
     if w.name in ("quantize", "quantize_rne", "dequant", "linear"):
         streams = None  # these reuse one output buffer per launch
@@ -713,7 +761,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+        with stdout_to_stderr():   # (RCCL's version banner goes to stdout when the communicator comes up)
+            dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+            t0 = torch.zeros(1, device=dev)
+            dist.all_reduce(t0)    # forces the communicator (and its banner) now
+            torch.cuda.synchronize(dev)
     if args.gpus != world and rank == 0:
         log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     L.load()
