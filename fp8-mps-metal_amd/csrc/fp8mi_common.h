@@ -126,16 +126,28 @@ FP8MI_DEVICE float epilogue_value(float sum, float sa, float sb, bool has_bias, 
 // the row's sum), then the four row sums are read out as scalars.  (The generic `__shfl_xor` butterfly compiles to six DEPENDENT
 // ds_bpermute_b32 + s_waitcnt pairs - ~100 cycles each - per reduced value: 24 of them in series sat in the tail of every workgroup
 // of the 4-row vec-mat, ~1 us of config C1's 5.2 us.)
+template <int CTRL>
+FP8MI_DEVICE float dpp_add(float x)   // x + (x of the lane the DPP control selects; 0 where that lane is inactive)
+{
+    const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false);
+    return x + __builtin_bit_cast(float, y);
+}
+
+// sum over aligned groups of P = 2 / 4 / 8 / 16 adjacent lanes (every lane of a group ends with the group's sum)
+template <int P>
+FP8MI_DEVICE float group_sum(float v)
+{
+    static_assert(P == 1 || P == 2 || P == 4 || P == 8 || P == 16, "a power of two inside a row of 16 lanes");
+    if (P >= 2) v = dpp_add<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+    if (P >= 4) v = dpp_add<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+    if (P >= 8) v = dpp_add<0x141>(v);   // row_half_mirror: lane i <- lane 7 - i of its half row
+    if (P >= 16) v = dpp_add<0x140>(v);  // row_mirror: lane i <- lane 15 - i of its row
+    return v;
+}
+
 FP8MI_DEVICE float wave_sum(float v)
 {
-    auto dpp_add = [](float x, auto ctrl) {
-        const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, false);
-        return x + __builtin_bit_cast(float, y);
-    };
-    v = dpp_add(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1, 0, 3, 2]
-    v = dpp_add(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2, 3, 0, 1]
-    v = dpp_add(v, std::integral_constant<int, 0x141>{});   // row_half_mirror: lane i <- lane 7 - i of its half row
-    v = dpp_add(v, std::integral_constant<int, 0x140>{});   // row_mirror: lane i <- lane 15 - i of its row
+    v = group_sum<16>(v);
     const int b = __builtin_bit_cast(int, v);
     const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)),
                 r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));

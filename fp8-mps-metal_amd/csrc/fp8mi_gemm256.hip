@@ -123,7 +123,7 @@ template <int COLS, int OUT, bool BIAS, bool TRANSPOSED, bool TABLES>
 FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8 *dump, lds_cf32 *tab, int half, int64_t m_wave, int64_t n_wave, int64_t ldc, int rows_ok, int cols_ok, int lane)
 {
     constexpr int kEsz = OUT == FP8MI_F32 ? 4 : 2;
-    constexpr int kBatch = 4;
+    constexpr int kBatch = (BIAS && !TABLES) ? 2 : 4;   // store instructions per batch (with a bias two batches of four in flight do not fit the registers the asm leaves)
     constexpr int kLpr = COLS / 8, kRpi = 64 / kLpr, kIters = 64 / kRpi;   // lanes per row, rows per instruction, instructions per half
     constexpr int kDumpRow = 16 * COLS * 4;
     const int pp = lane % kLpr, rsub = lane / kLpr;
@@ -220,7 +220,7 @@ FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8
     };
     constexpr int kTrips = kIters / kBatch;
     static_assert(kIters % kBatch == 0 && kTrips >= 1, "whole batches");
-    constexpr bool kPipe = !(TABLES || BIAS) && kTrips >= 2;   // (with tables / bias two batches in flight do not fit the ~118 registers the asm leaves)
+    constexpr bool kPipe = !TABLES && kTrips >= 2;   // (with per-row scale tables two batches in flight do not fit the ~118 registers the asm leaves)
     if constexpr (kPipe) {
         Batch A, Bq;
         load(0, A);

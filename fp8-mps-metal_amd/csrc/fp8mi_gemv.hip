@@ -342,7 +342,12 @@ __global__ __launch_bounds__(kWaves * 64) void gemv_mx_kernel(MMParams p_in)
     __syncthreads();
 
     int dirty = 0;
-    const int cm = threadIdx.x / kRows, cr = threadIdx.x % kRows;  // this thread's output cell (threads 0 .. MX*kRows-1)
+    // kP adjacent lanes per output cell: each adds its share of the cell's kWaves x 16 lane sums, a DPP group sum finishes (round 3: one thread per
+    // cell added 64-128 LDS values in series in the tail of every workgroup)
+    constexpr int kCells = MX * kRows, kVals = kWaves * 16;
+    constexpr int kP = kThreads / kCells >= 16 ? 16 : (kThreads / kCells >= 8 ? 8 : (kThreads / kCells >= 4 ? 4 : (kThreads / kCells >= 2 ? 2 : 1)));
+    const int cell = threadIdx.x / kP, cj = threadIdx.x % kP;
+    const int cm = cell / kRows, cr = cell % kRows;  // this thread's output cell
     auto finish = [&](int m, int r, float sum) {
         const int64_t n = rown(r);
         const float sa = p.sa_row ? p.scale_a[m] : sa0;
@@ -352,15 +357,19 @@ __global__ __launch_bounds__(kWaves * 64) void gemv_mx_kernel(MMParams p_in)
                          epilogue_value(sum, sa, sw, p.bias != nullptr, b, p.scale_result != nullptr, sr, p.transposed != 0), p.out_dtype);
     };
     static_assert(MX * kRows <= kThreads, "one thread per output cell of the workgroup");
-    if (threadIdx.x < MX * kRows) {
+    if (threadIdx.x < kCells * kP) {   // (whole groups of kP lanes: kCells * kP is a multiple of kP)
         float sum = 0.0f;
 #pragma unroll
-        for (int wv = 0; wv < kWaves; ++wv)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) sum += part[wv][cm][cr][j];
+        for (int v = 0; v < kVals / kP; ++v) {
+            const int i = v * kP + cj;
+            sum += part[i >> 4][cm][cr][i & 15];
+        }
+        sum = group_sum<kP>(sum);
         dirty = (p.nan_zero && sum != sum) ? 1 : 0;
-        dirty_cell[cm][cr] = dirty;
-        if (cm < M && rown(cr) < p.N && !dirty) finish(cm, cr, sum);
+        if (cj == 0) {
+            dirty_cell[cm][cr] = dirty;
+            if (cm < M && rown(cr) < p.N && !dirty) finish(cm, cr, sum);
+        }
     }
     if (!__syncthreads_or(dirty)) return;
 
