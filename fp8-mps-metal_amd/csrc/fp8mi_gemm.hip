@@ -616,7 +616,8 @@ int fp8mi_choose_gemm_variant(const MMParams &p)
         // round (FLUX: 40.8 us per tile at nk = 24, in-kernel stamps) against 8 + 1.6 nk for the ring kernel
         const bool w256 = fp8mi_gemm256_supported(p);
         const double us256 = rounds(t256, cus, 0.75, 0.25) * (w256 ? 8.5 + 1.35 * nk : 8.0 + 1.6 * nk);  // (a quarter-filled round of 256x256
-        const double us128 = rounds(t128, 2 * cus, 0.55, 0.45) * (5.5 + 0.87 * nk);  //  tiles still costs 0.8 of a full one)
+        const double us128 = rounds(t128, 2 * cus, 0.55, 0.45) * (5.5 + 1.0 * nk);   //  tiles still costs 0.8 of a full one; 128x128: 0.95-1.07 us per K-step and round in round 3's
+                                                                                    //  sweep - profiles/r03_large_m.txt - where round 1 fitted 0.87: at 0.87 AUTO took it for 2048x12288x3072 at 117 us, 256x128W 75)
         const double us64 = rounds(t64, cus, 0.6, 0.4) * (5.0 + 0.37 * nk);
         // ... and its 256x128 form at max(1.5 + 0.89 nk, 4.5 + 0.75 nk) per round (deep K: the DMA stream; shallow K: the per-tile
         // fixed cost), a partly filled round costing nearly a full one (fitted: 2048x4096x4096 29.8 us, 1024x8192x8192 58.5,

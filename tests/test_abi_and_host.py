@@ -283,7 +283,7 @@ def test_automatic_dispatch_table():
     assert pick(4173, 3072, 12296) == L.KERNEL_GEMM_256W                                           # ragged M and N stay on it
     assert pick(2048, 4096, 4096) == L.KERNEL_GEMM_256x128W and pick(4096, 3072, 1536) == L.KERNEL_GEMM_256x128W   # < 1 round of 256x256
     assert pick(1536, 3072, 4096) == L.KERNEL_GEMM_256x128W                                        # the 8-GPU shard, transposed
-    assert pick(1024, 4096, 4096) == L.KERNEL_GEMM_128
+    assert pick(1024, 4096, 4096) == L.KERNEL_GEMM_256x128W and pick(768, 3072, 3072) == L.KERNEL_GEMM_128    # (round 3: 29.3 against 31.2 us on 128x128 tiles; 128x128 keeps small square shapes)
     assert pick(16384, 1024, 8192) == L.KERNEL_GEMM_256W                                           # shallow K: per-tile fixed cost decides
     assert pick(4096, 3088, 12288) == L.KERNEL_GEMM_256W                                           # K tail: staged with per-lane masks since round 3
     assert pick(4096, 3072, 12292) in (L.KERNEL_GEMM_256, L.KERNEL_GEMM_128)                       # N not a multiple of 8 half columns: a ring kernel

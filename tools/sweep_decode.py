@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Decode regime (9 <= M <= 64 against deep K): AUTO vs forced tile kernels with the automatic K split.
-    [FP8MI_LIB_PATH=.../libfp8mi_diag.so] python tools/sweep_decode.py [kernel ids ...]"""
+"""AUTO vs forced tile kernels with the automatic K split over (K, N) x M grids (default: the decode regime, 9 <= M <= 128 against deep K).
+    [FP8MI_LIB_PATH=.../libfp8mi_diag.so] [MS=512,1024] [KN=4096x4096,3072x12288] python tools/sweep_decode.py [kernel ids ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "fp8-mps-metal_amd")]
@@ -11,6 +11,8 @@ st = torch.cuda.current_stream().cuda_stream
 s1 = torch.full((1,), 0.01, device=dev)
 g = torch.Generator(device=dev).manual_seed(1)
 KN = [(14336, 4096), (8192, 8192), (4096, 14336), (12288, 3072), (4096, 4096), (7168, 7168)]
+if os.environ.get("KN"):   # e.g. KN=4096x4096,3072x12288 (K x N)
+    KN = [tuple(int(v) for v in kn.split("x")) for kn in os.environ["KN"].split(",")]
 MS = [int(x) for x in os.environ.get("MS", "9,16,32,48,64,96,128").split(",")]
 ids = [int(x) for x in sys.argv[1:]] or [0, L.KERNEL_GEMM_64x128, L.KERNEL_GEMM_128x64]
 for (K, N) in KN:
