@@ -78,10 +78,31 @@ static int choose_kernel(const MMParams &p)
 {
     if (fp8mi_gemv_supported(p)) return FP8MI_KERNEL_GEMV;
     if (p.M >= 3 && p.M <= 8 && p.K <= 6144 && fp8mi_gemm_supported(p) && (p.N + 63) / 64 >= fp8mi_cu_count() / 2) {
-        // a few rows against a WIDE, shallow weight matrix: N alone fills the chip with unsplit 32x64 tiles, which stream W through the LDS-DMA ring
+        // a few rows against a WIDE, shallow weight matrix: N alone fills the chip with unsplit 32-row tiles, which stream W through the LDS-DMA ring
         // while the few-rows kernel re-reads x per group of weight rows (round 3, tools/time_shape.py: M=4 K=4096 N=14336 12.1 against 14.6 us,
-        // M=8 11.9 against 14.8; M=4 K=3072 N=12288 8.8 against 12.1; M=8 K=4096 N=8192 9.8 against 13.0; M=2: equal, stays below)
-        return FP8MI_KERNEL_GEMM_32x64;
+        // M=8 11.9 against 14.8; M=4 K=3072 N=12288 8.8 against 12.1; M=8 K=4096 N=8192 9.8 against 13.0; M=2: equal, stays below); up to N = 8192 the
+        // 32x32 tile (twice the workgroups; K=2048 N=8192 M=4: 5.6 against 7.8 us)
+        // (beyond one round of 64-column tiles - N > 64 CUs - 64x128 tiles: K=4096 N=28672 M=8 18.4 against 20.2 us)
+        if ((p.N + 63) / 64 > fp8mi_cu_count()) return FP8MI_KERNEL_GEMM_64x128;
+        return p.N <= 8192 ? FP8MI_KERNEL_GEMM_32x32 : FP8MI_KERNEL_GEMM_32x64;
+    }
+    if (p.M >= 5 && p.M <= 128 && p.K >= 2048 && p.ws && p.split != 1 && fp8mi_gemm_supported(p) && (double)p.N * (double)p.K >= 12.0 * 1048576.0) {
+        // The small-batch regime on the SMALL tile kernels with the automatic K split (round 3; tools/sweep_decode.py on MI355X, six (K, N)
+        // from 4096^2 to 14336 x 4096, M = 9 .. 128): 32x64 tiles for M <= 32 (K=14336 N=4096: 12.9-13.2 us against 16.5-17.2 on 64x128 x 8
+        // slices; K=12288 N=3072 11.4 against 15.8-16.2; K=N=4096 8.2-8.4 against the skinny kernel's 8.5-10.2), 64x64 tiles for M <= 64
+        // (14.3-14.9 against 17.2-17.4) and on to M = 128 while 128x64 tiles would leave half the CUs idle (K=N=4096 M=96: 9.5 against 13.2;
+        // K=N=8192 M=96: 19.0 against 22.5) - except M > 96 against K > 8192, where 128x64 x split stays 3-6 % ahead.
+        // From M = 5 (the LLM-shape sweep, profiles/r03_llm_shapes.txt: M=8 K=13824 N=5120 14.6 against 26.6 us on the few-rows kernel, K=4096 N=6144 7.7
+        // against 11.8; M <= 4 stays there).  A matrix so wide that 64-column tiles need more than one round (N > 64 CUs) takes 64x128 tiles for M <= 64
+        // (K=5120 N=27648 M=64: 26.9 against 32.8 us).
+        const int64_t cus = fp8mi_cu_count(), t64 = ((p.M + 127) / 128) * ((p.N + 63) / 64);
+        if (p.M <= 64 && (p.N + 63) / 64 > cus) return FP8MI_KERNEL_GEMM_64x128;
+        // ... and 32x32 tiles where K and N stay within 8192: twice the tiles = half the K slices (none at N = 8192), the partial exchange being what the
+        // regime pays for (K=N=8192 M=32: 14.7 against 18.0 us; K=N=4096: 7.2 against 8.1); against a deeper K their doubled x traffic loses (K=12288 N=3072: 12.3 against 11.6)
+        if (p.M <= 32) return (p.N <= 8192 && p.K <= 8192) ? FP8MI_KERNEL_GEMM_32x32 : FP8MI_KERNEL_GEMM_32x64;
+        if (p.M <= 64 && (double)p.N * (double)p.K <= 16.0 * 1048576.0) return FP8MI_KERNEL_GEMM_32x32;   // (K=N=4096, M=48-64: 7.6 against 9.4 us on 64x64)
+        if (p.M <= 64) return FP8MI_KERNEL_GEMM_64x64;
+        if (t64 <= cus / 2 && !(p.M > 96 && p.K > 8192)) return FP8MI_KERNEL_GEMM_64x64;
     }
     if (fp8mi_gemv_mx_supported(p)) {
         // 2..8 rows of x on the vec-mat's weight-streaming structure (tools/check_gemv_mx.py time, MI355X): ahead of
@@ -90,20 +111,6 @@ static int choose_kernel(const MMParams &p)
         // cannot fill the chip with (K = 14336, N = 4096: 14.3 vs 17.4 us; K = N = 8192: 15.1 vs 17.9 us)
         const int64_t t64 = (p.N + 63) / 64, cus = fp8mi_cu_count();
         if (p.M <= 4 || (p.K > 4096 && t64 < (3 * cus) / 4)) return FP8MI_KERNEL_GEMV_MX;
-    }
-    if (p.M >= 9 && p.M <= 128 && p.K >= 2048 && p.ws && p.split != 1 && fp8mi_gemm_supported(p) && (double)p.N * (double)p.K >= 12.0 * 1048576.0) {
-        // The small-batch regime on the SMALL tile kernels with the automatic K split (round 3; tools/sweep_decode.py on MI355X, six (K, N)
-        // from 4096^2 to 14336 x 4096, M = 9 .. 128): 32x64 tiles for M <= 32 (K=14336 N=4096: 12.9-13.2 us against 16.5-17.2 on 64x128 x 8
-        // slices; K=12288 N=3072 11.4 against 15.8-16.2; K=N=4096 8.2-8.4 against the skinny kernel's 8.5-10.2), 64x64 tiles for M <= 64
-        // (14.3-14.9 against 17.2-17.4) and on to M = 128 while 128x64 tiles would leave half the CUs idle (K=N=4096 M=96: 9.5 against 13.2;
-        // K=N=8192 M=96: 19.0 against 22.5) - except M > 96 against K > 8192, where 128x64 x split stays 3-6 % ahead.
-        const int64_t cus = fp8mi_cu_count(), t64 = ((p.M + 127) / 128) * ((p.N + 63) / 64);
-        // ... and 32x32 tiles where K and N stay within 8192: twice the tiles = half the K slices (none at N = 8192), the partial exchange being what the
-        // regime pays for (K=N=8192 M=32: 14.7 against 18.0 us; K=N=4096: 7.2 against 8.1); against a deeper K their doubled x traffic loses (K=12288 N=3072: 12.3 against 11.6)
-        if (p.M <= 32) return (p.N <= 8192 && p.K <= 8192) ? FP8MI_KERNEL_GEMM_32x32 : FP8MI_KERNEL_GEMM_32x64;
-        if (p.M <= 64 && (double)p.N * (double)p.K <= 16.0 * 1048576.0) return FP8MI_KERNEL_GEMM_32x32;   // (K=N=4096, M=48-64: 7.6 against 9.4 us on 64x64)
-        if (p.M <= 64) return FP8MI_KERNEL_GEMM_64x64;
-        if (t64 <= cus / 2 && !(p.M > 96 && p.K > 8192)) return FP8MI_KERNEL_GEMM_64x64;
     }
     if (p.M >= 2 && p.M <= 48 && fp8mi_skinny_supported(p)) {
         // measured (tools/sweep_small_m.py): on small weight matrices the weight-streaming skinny kernel wins up

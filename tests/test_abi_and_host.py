@@ -268,9 +268,11 @@ def test_automatic_dispatch_table():
 
     assert pick(1, 4096, 4096) == L.KERNEL_GEMV and pick(1, 14336, 4096) == L.KERNEL_GEMV          # configs C1, C2
     assert pick(4, 4096, 4096) == L.KERNEL_GEMV_MX and pick(2, 4096, 14336) == L.KERNEL_GEMV_MX    # the reference's batch-4 shape
-    assert pick(8, 14336, 4096) == L.KERNEL_GEMV_MX and pick(8, 4096, 4096) == L.KERNEL_SKINNY     # 5..8 rows: deep K only
-    assert pick(6, 4096, 14336) == L.KERNEL_GEMM_32x64 and pick(4, 3072, 12288, ws=0) == L.KERNEL_GEMM_32x64   # wide shallow N fills the chip with unsplit 32x64 tiles
-    assert pick(6, 8192, 8192) == L.KERNEL_GEMV_MX                                                 # ... deep K stays on the few-rows kernel
+    assert pick(8, 14336, 4096) == L.KERNEL_GEMM_32x64 and pick(8, 4096, 4096) == L.KERNEL_GEMM_32x32   # 5..8 rows: the small tiles with the K split (round 3)
+    assert pick(8, 14336, 4096, ws=0) == L.KERNEL_GEMV_MX and pick(8, 4096, 4096, ws=0) == L.KERNEL_SKINNY   # ... without a workspace: few-rows kernel (deep K) / skinny
+    assert pick(4, 14336, 4096) == L.KERNEL_GEMV_MX and pick(64, 5120, 27648) == L.KERNEL_GEMM_64x128   # M <= 4 stays; more than a round of 64-column tiles: 64x128
+    assert pick(6, 4096, 14336) == L.KERNEL_GEMM_32x64 and pick(4, 3072, 12288, ws=0) == L.KERNEL_GEMM_32x64   # wide shallow N fills the chip with unsplit 32-row tiles
+    assert pick(4, 2048, 8192) == L.KERNEL_GEMM_32x32 and pick(4, 8192, 8192) == L.KERNEL_GEMV_MX   # ... 32x32 up to N = 8192; deep K and M <= 4 stay on the few-rows kernel
     assert pick(32, 4096, 4096) == L.KERNEL_GEMM_32x32 and pick(32, 2048, 2048) == L.KERNEL_SKINNY   # small matrices stay on the skinny kernel
     assert pick(16, 8192, 8192) == L.KERNEL_GEMM_32x32 and pick(64, 4096, 4096) == L.KERNEL_GEMM_32x32   # K, N <= 8192: more tiles, fewer K slices
     assert pick(32, 4096, 4096, ws=0) == L.KERNEL_SKINNY and pick(32, 4096, 4096, split=1) == L.KERNEL_SKINNY   # the small tiles live on the K split
