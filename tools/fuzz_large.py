@@ -12,7 +12,7 @@ cases = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 dev = torch.device("cuda:0"); rng = np.random.default_rng(seed); g = torch.Generator(device=dev).manual_seed(seed)
 bad = 0
 for it in range(cases):
-    M = int(rng.integers(700, 6000)); N = 8 * int(rng.integers(100, 1200)); K = 128 * int(rng.integers(2, 40))
+    M = int(rng.integers(700, 6000)); N = 8 * int(rng.integers(100, 1200)); K = 128 * int(rng.integers(2, 40)) + (16 * int(rng.integers(1, 8)) if rng.random() < 0.3 else 0)   # (round 3: K tails too)
     A = torch.randint(0, 0x7F, (M, K), dtype=torch.uint8, device=dev, generator=g)
     B = torch.randint(0, 0x7F, (N, K), dtype=torch.uint8, device=dev, generator=g)
     if rng.random() < 0.3: A[int(rng.integers(M)), int(rng.integers(K))] = 0x7F          # NaN byte: scrubbing redo of one tile
