@@ -63,6 +63,31 @@ FP8MI_DEVICE MMParams pin_params(const MMParams &p)
     return q;
 }
 
+// Cache policy of the GEMM kernels' C stores (compile-time knob for A/B builds; the product value is the default below):
+//   0 default (write-back)   1 nt (streaming)   2 sc0 sc1 (system scope: written THROUGH the XCD's L2)   3 sc0 sc1 nt   4 sc1   5 sc1 nt
+// The end of a kernel is an agent-scope release, which on this 8-L2 part means a write-back of every dirty line of
+// every L2: stores that are written through leave nothing for it.
+#ifndef FP8MI_CSTORE
+#define FP8MI_CSTORE 1
+#endif
+constexpr int kCStoreAux = FP8MI_CSTORE == 0 ? 0 : FP8MI_CSTORE == 1 ? 2 : FP8MI_CSTORE == 2 ? 17 : FP8MI_CSTORE == 3 ? 19 : FP8MI_CSTORE == 4 ? 16 : 18;
+FP8MI_DEVICE void store_c16(u32x4 q, void *ptr)   // one 16-byte piece of C
+{
+#if FP8MI_CSTORE == 0
+    *(u32x4 *)ptr = q;
+#elif FP8MI_CSTORE == 1
+    __builtin_nontemporal_store(q, (u32x4 *)ptr);
+#elif FP8MI_CSTORE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(q) : "memory");
+#elif FP8MI_CSTORE == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(ptr), "v"(q) : "memory");
+#elif FP8MI_CSTORE == 4
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(q) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(ptr), "v"(q) : "memory");
+#endif
+}
+
 // SWAR scrub: zero every byte of w whose low 7 bits are all ones (the two
 // e4m3fn NaN patterns 0x7F / 0xFF), i.e. the reference's decode rule
 // "NaN -> 0.0" (fp8_matmul.metal:21) applied to four packed bytes.

@@ -127,12 +127,19 @@ FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8
     constexpr int kLpr = COLS / 8, kRpi = 64 / kLpr, kIters = 64 / kRpi;   // lanes per row, rows per instruction, instructions per half
     constexpr int kDumpRow = 16 * COLS * 4;
     const int pp = lane % kLpr, rsub = lane / kLpr;
+    // fp32 output (round 3): a lane's 32 bytes would go out as two 16-byte stores that each leave 16-byte holes in every line they touch
+    // (streamed through the L2 on a 256 MiB C that cost 14 %: M = N = K = 8192 525 us against 450 with write-back stores).  Instead a lane
+    // takes ONE 16-byte chunk (position P) from each of two rows kRpiF apart, so that each store instruction writes kRpiF whole rows.
+    constexpr bool kF32 = OUT == FP8MI_F32;
+    constexpr int kLprF = COLS / 4, kRpiF = 64 / kLprF;
+    const int P = lane % kLprF, rsubF = lane / kLprF;
+    auto chunk_col = [&](int r) { return (2 * (((P >> 1) ^ (r >> 1)) & (kLpr - 1)) + ((P ^ r) & 1)) * 4; };   // first column of the chunk at position P of row r
     // the wave tile of C as a raw buffer: 32-bit offsets in the store instead of 64-bit pointer arithmetic per row
     // (num_records = the wave tile's valid rows: stores to rows of a ragged last m-tile beyond M are out of range and dropped)
     __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)((uint8_t *)p.C + (m_wave * ldc + n_wave) * kEsz), 0,
                                                                   (int)((int64_t)rows_ok * ldc * kEsz), 0x00020000);
 #ifndef FP8MI_EPI_AUX
-#define FP8MI_EPI_AUX 2
+#define FP8MI_EPI_AUX kCStoreAux
 #endif
     constexpr int kNt = FP8MI_EPI_AUX;             // aux: streaming (nt) store - C is written once and not re-read here (0 = default policy: A/B builds only)
     const uint32_t ldc_b = (uint32_t)(ldc * kEsz);
@@ -145,11 +152,33 @@ FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8
     // FLUX only gets 2 % faster, so the epilogue's 11.4 k cycles per tile are its own instruction stream, not the store traffic).
     struct Batch {
         f32x4 q0[kBatch], q1[kBatch], sb0[kBatch], sb1[kBatch], bn0[kBatch], bn1[kBatch];
-        float sa[kBatch], bm[kBatch];
+        float sa[kBatch], bm[kBatch], sa1[kBatch], bm1[kBatch];   // (sa1 / bm1: the second row of the fp32 form)
     };
     auto load = [&](int it0, Batch &B) {
 #pragma unroll
         for (int b = 0; b < kBatch; ++b) {
+            if constexpr (kF32) {
+                const int rrA = (it0 + b) * kRpi + rsubF, rrB = rrA + kRpiF, rA = rrA & 15, rB = rrB & 15;
+                lds_cu8 *base = dump + (rrA >> 4) * kDumpRow + P * 16;
+                B.q0[b] = *(lds_cf32x4 *)(base + rA * (COLS * 4));
+                B.q1[b] = *(lds_cf32x4 *)(base + rB * (COLS * 4));
+                const int colA = chunk_col(rA), colB = chunk_col(rB), rowA = half * 64 + rrA, rowB = half * 64 + rrB;
+                if (TABLES) {
+                    B.sa[b] = tab[rowA];
+                    B.sa1[b] = tab[rowB];
+                    B.sb0[b] = *(lds_cf32x4 *)(tab + 128 + colA);
+                    B.sb1[b] = *(lds_cf32x4 *)(tab + 128 + colB);
+                }
+                if (BIAS && !TRANSPOSED) {
+                    B.bn0[b] = *(lds_cf32x4 *)(tab + 256 + colA);
+                    B.bn1[b] = *(lds_cf32x4 *)(tab + 256 + colB);
+                }
+                if (BIAS && TRANSPOSED) {
+                    B.bm[b] = tab[384 + rowA];
+                    B.bm1[b] = tab[384 + rowB];
+                }
+                continue;
+            }
             const int rr = (it0 + b) * kRpi + rsub, r = rr & 15;   // row inside the half: fragment row rr >> 4, row r
             lds_cu8 *src = dump + (rr >> 4) * kDumpRow + r * (COLS * 4) + pp * 32;
             const int swap = (r & 1) * 16;                      // odd rows hold the pair's chunks exchanged: undo it in the address
@@ -177,10 +206,10 @@ FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float a = j < 4 ? lo[j & 3] : hi[j & 3];
-                const float s_a = TABLES ? B.sa[b] : sa_u;
+                const float s_a = TABLES ? ((kF32 && j >= 4) ? B.sa1[b] : B.sa[b]) : sa_u;
                 const float s_b = TABLES ? (j < 4 ? B.sb0[b][j & 3] : B.sb1[b][j & 3]) : sb_u;
                 float x = TRANSPOSED ? (a * s_b) * s_a : (a * s_a) * s_b;
-                if (BIAS) x = x + (TRANSPOSED ? B.bm[b] : (j < 4 ? B.bn0[b][j & 3] : B.bn1[b][j & 3]));
+                if (BIAS) x = x + (TRANSPOSED ? ((kF32 && j >= 4) ? B.bm1[b] : B.bm[b]) : (j < 4 ? B.bn0[b][j & 3] : B.bn1[b][j & 3]));
                 v[b][j] = x;
             }
         }
@@ -192,15 +221,20 @@ FP8MI_DEVICE f32x4 epilogue_half(const MMParams &p, int flags, float sr, lds_cu8
         }
 #pragma unroll
         for (int b = 0; b < kBatch; ++b) {
+            if constexpr (kF32) {
+                const int rrA = (it0 + b) * kRpi + rsubF, rrB = rrA + kRpiF;
+                const int colA = chunk_col(rrA & 15), colB = chunk_col(rrB & 15);
+                const int offA = colA < cols_ok ? (int)((uint32_t)(half * 64 + rrA) * ldc_b + (uint32_t)(colA * 4)) : 0x7FFFFFF0;
+                const int offB = colB < cols_ok ? (int)((uint32_t)(half * 64 + rrB) * ldc_b + (uint32_t)(colB * 4)) : 0x7FFFFFF0;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[b][0], v[b][1], v[b][2], v[b][3]}), rc, offA, 0, kNt);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[b][4], v[b][5], v[b][6], v[b][7]}), rc, offB, 0, kNt);
+                continue;
+            }
             const int rr = (it0 + b) * kRpi + rsub, r = rr & 15;
             const int col = ((pp ^ (r >> 1)) & (kLpr - 1)) * 8, row = half * 64 + rr;
             // columns of a ragged last n-tile beyond N: the store's offset is pushed out of the descriptor's range (dropped)
             const int off = col < cols_ok ? (int)((uint32_t)row * ldc_b + (uint32_t)(col * kEsz)) : 0x7FFFFFF0;
-            if (OUT == FP8MI_F32) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[b][0], v[b][1], v[b][2], v[b][3]}), rc, off, 0, kNt);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[b][4], v[b][5], v[b][6], v[b][7]}), rc,
-                                                       col + 4 < cols_ok ? off + 16 : 0x7FFFFFF0, 0, kNt);
-            } else {
+            {
                 uint32_t w[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {   // one packed convert (round to nearest even) per output pair

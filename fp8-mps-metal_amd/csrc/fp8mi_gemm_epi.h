@@ -167,7 +167,7 @@ FP8MI_DEVICE void epilogue_staged(const MMParams &p, const EpiScalars &es, const
             u32x4 q = *(const u32x4 *)(buf + r * kStride + rchunk * 16);
             // streaming store: C is written once and not re-read by this kernel, so it should not displace the
             // A / B panels in L2 (measured: C3 -3 %, 128x128 shard -5 %, FLUX -1 %)
-            __builtin_nontemporal_store(q, (u32x4 *)(grow + (int64_t)r * p.ldc * kEsz + rchunk * 16));
+            store_c16(q, grow + (int64_t)r * p.ldc * kEsz + rchunk * 16);
         }
     }
 }
