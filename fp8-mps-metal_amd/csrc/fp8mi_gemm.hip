@@ -624,7 +624,10 @@ int fp8mi_choose_gemm_variant(const MMParams &p)
         // 4096x3072x1536 23.3, 3072^3 45.6, FLUX 136.8, 16384x1024x8192 168.6; profiles/r02_large_shapes.txt)
         const double t256n = (double)(((p.M + 255) / 256) * ((p.N + 127) / 128));
         const double per256n = 1.5 + 0.89 * nk > 4.5 + 0.75 * nk ? 1.5 + 0.89 * nk : 4.5 + 0.75 * nk;
-        const double us256n = w256 ? rounds(t256n, cus, 0.85, 0.15) * per256n : 1e30;
+        // (one row of 256x128 tiles on at most half of the CUs: nobody shares a B panel, every CU streams its own from HBM at what ONE CU keeps in
+        //  flight - M = 192 K = 4096 N = 14336: 35.3 us against 28.7 on 128x64 tiles, M = 256 K = 3072 N = 12288: 28.7 against 25.7)
+        const bool lone_row = p.M <= 256 && t256n <= cus / 2;
+        const double us256n = (w256 && !lone_row) ? rounds(t256n, cus, 0.85, 0.15) * per256n : 1e30;
         if (t64 <= cus / 2) {
             // few tiles: one per CU at most, split-K (launch<>) fills the rest of the chip when a workspace came along;
             // with few rows of A the tile is better spent on N
