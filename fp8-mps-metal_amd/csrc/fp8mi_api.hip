@@ -101,6 +101,9 @@ static int choose_kernel(const MMParams &p)
         // regime pays for (K=N=8192 M=32: 14.7 against 18.0 us; K=N=4096: 7.2 against 8.1); against a deeper K their doubled x traffic loses (K=12288 N=3072: 12.3 against 11.6)
         if (p.M <= 32) return (p.N <= 8192 && p.K <= 8192) ? FP8MI_KERNEL_GEMM_32x32 : FP8MI_KERNEL_GEMM_32x64;
         if (p.M <= 64 && (double)p.N * (double)p.K <= 16.0 * 1048576.0) return FP8MI_KERNEL_GEMM_32x32;   // (K=N=4096, M=48-64: 7.6 against 9.4 us on 64x64)
+        // (33..64 rows against N = 8192-ish: two rows of 32x64 tiles are one whole round with NO K split, i.e. no partial exchange, where 64x64 tiles need
+        //  2 slices - K=N=8192 M=33 / 48 / 64: 15.7 / 17.4 / 18.0 against 19.3 / 19.2 / 19.1 us, K=4096 9.4-10.5 against 10.4-10.8; at N = 7936, 248 tiles, 64x64 x 2 is 6 % ahead again and stays)
+        if (p.M <= 64 && p.K <= 8192 && 2 * ((p.N + 63) / 64) <= cus && 2 * ((p.N + 63) / 64) > cus - 4) return FP8MI_KERNEL_GEMM_32x64;
         if (p.M <= 64) return FP8MI_KERNEL_GEMM_64x64;
         if (t64 <= cus / 2 && !(p.M > 96 && p.K > 8192)) return FP8MI_KERNEL_GEMM_64x64;
     }

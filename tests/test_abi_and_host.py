@@ -284,6 +284,7 @@ def test_automatic_dispatch_table():
     assert pick(4096, 3072, 12288) == L.KERNEL_GEMM_256W and pick(8192, 8192, 8192) == L.KERNEL_GEMM_256W   # FLUX, 8192^3
     assert pick(4173, 3072, 12296) == L.KERNEL_GEMM_256W                                           # ragged M and N stay on it
     assert pick(2048, 4096, 4096) == L.KERNEL_GEMM_256x128W and pick(4096, 3072, 1536) == L.KERNEL_GEMM_256x128W   # < 1 round of 256x256
+    assert pick(64, 8192, 8192) == L.KERNEL_GEMM_32x64 and pick(64, 7168, 7168) == L.KERNEL_GEMM_64x64   # N = 8192: two rows of 32x64 tiles = one whole unsplit round
     # one row of 256x128 tiles on at most half of the CUs streams every B panel unshared: the ring kernel's smaller tiles instead
     assert pick(192, 4096, 14336) == L.KERNEL_GEMM_128x64 and pick(256, 3072, 12288) == L.KERNEL_GEMM_128x64
     assert pick(256, 4096, 28672) == L.KERNEL_GEMM_256x128W   # ... but not when that one row covers most of the chip
