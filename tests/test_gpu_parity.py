@@ -645,6 +645,35 @@ def test_gemm256w_random_shapes(native, cuda, oracle, wk):
         assert torch.equal(got, ref), (M, K, N, od)
 
 
+@pytest.mark.parametrize("wk", [L.KERNEL_GEMM_256W, L.KERNEL_GEMM_256x128W])
+@pytest.mark.parametrize("M,K,N", [(300, 384, 260), (256, 512, 12), (513, 640, 1020), (130, 400, 132), (256, 256, 4)])
+def test_gemm256w_fp32_rows_with_n_a_multiple_of_4(native, cuda, oracle, M, K, N, wk):
+    """fp32 output only needs N % 4 == 0 (16-byte stores).  The fp32 epilogue takes ONE 4-column chunk from each of two rows per lane (so that
+    a store instruction writes whole rows): a last chunk that starts at N - 4 must be written, the next one dropped - ragged N that is not a
+    multiple of 8, every epilogue form, against the oracle and the ring kernel's bits; the guard columns beyond N (ldc > N) stay untouched."""
+    rng = np.random.default_rng(M * 7 + K + N)
+    A = clean_bytes(rng, (M, K))
+    B = clean_bytes(rng, (N, K))
+    sa = rng.uniform(0.005, 0.02, size=M).astype(np.float32)
+    sb = rng.uniform(0.005, 0.02, size=N).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    bias_m = rng.standard_normal(M).astype(np.float32)
+    tA, tB = dev(A, cuda), dev(B, cuda)
+    check_mm(oracle, native, cuda, A, B, [0.01], [0.02], kernel=wk)
+    check_mm(oracle, native, cuda, A, B, sa, sb, kernel=wk, bias=bias, scale_result=0.25)
+    s1, sN, sM = torch.full((1,), 0.01), dev(sb, cuda), dev(sa, cuda)
+    forms = [dict(scale_a=s1, scale_b=s1), dict(scale_a=sM, scale_b=sN, bias=dev(bias, cuda)),
+             dict(scale_a=s1, scale_b=sN, bias=dev(bias, cuda, torch.bfloat16), scale_result=torch.full((1,), 0.5)),
+             dict(scale_a=sM, scale_b=sN, bias=dev(bias_m, cuda), transposed_epilogue=True)]
+    for kw in forms:
+        a = native.fp8_scaled_mm(tA, tB, kernel=wk, **kw)
+        b = native.fp8_scaled_mm(tA, tB, kernel=L.KERNEL_GEMM_256, split_k=1, **kw)
+        assert torch.equal(a, b), kw.keys()
+        wide = torch.full((M, N + 12), -7.0, device=cuda)          # ldc = N + 12: the columns beyond N belong to the caller
+        native.fp8_scaled_mm(tA, tB, kernel=wk, out=wide[:, :N], **kw)
+        assert torch.equal(wide[:, :N], b) and bool((wide[:, N:] == -7.0).all()), kw.keys()
+
+
 def test_gemm256w_envelope_dispatch_and_exactness(native, cuda, oracle):
     """Outside whole tiles / K-steps the explicit id refuses and AUTO falls back to the ring kernels; inside, AUTO picks it
     for large shapes (same bits either way); operands within a 2^12 product range are summed exactly by the matrix core,
