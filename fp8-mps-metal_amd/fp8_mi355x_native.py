@@ -365,6 +365,28 @@ def fp8_linear(x: torch.Tensor, weight_u8: torch.Tensor, weight_scale: torch.Ten
     return y.reshape(*x.shape[:-1], weight_u8.shape[0])
 
 
+def pad_weight_rows(weight: torch.Tensor, pad_bytes: int = 256) -> torch.Tensor:
+    """The same (N, K) fp8 / uint8 weight in a buffer whose ROW STRIDE is K + pad_bytes (a one-time copy at load time).  No counterpart
+    in the reference (its kernels take no strides); the C ABI and every Python entry point here take the stride as it is (`ldb`):
+    pass the returned view, or its `.t()` to the patched torch._scaled_mm.  Results are bit-identical to the unpadded call.
+
+    Why: the small-batch tile kernels stream W as 8-row x 128-byte pieces, and with some power-of-two-ish row strides those pieces
+    crowd onto few memory channels.  Measured on MI355X for M <= 128 (tools/sweep_pad.py, profiles/r03_row_stride.txt), +256 bytes:
+    K = 16384, N = 4096: 18.5 -> 14.3 us at M = 16 (19.6 -> 16.0 at M = 64); K = N = 8192: 14.2 -> 12.4 (18.1 -> 16.8);
+    K = N = 16384: 55.6 -> 45.9; K = 20480, N = 4096: 21.0 -> 17.0 at M = 64.  It is NOT a rule of K alone: K = 8192 against
+    N = 4096 or 14336, K = 4096, 14336, 24576, 28672 and every M >= 512 do not change, and K = 32768 gets 23 % SLOWER with 256
+    (unchanged with 512).  Measure the deployment's shapes with tools/sweep_pad.py before padding a model's weights."""
+    assert weight.dim() == 2 and weight.element_size() == 1, "an (N, K) matrix of fp8 bytes"
+    assert pad_bytes >= 0 and pad_bytes % 16 == 0, "the tile kernels need 16-byte aligned rows"
+    if pad_bytes == 0:
+        return weight
+    N, K = weight.shape
+    buf = torch.empty((N, K + pad_bytes), dtype=torch.uint8, device=weight.device)
+    view = buf[:, :K]
+    view.copy_(weight.view(torch.uint8) if weight.dtype != torch.uint8 else weight)
+    return view if weight.dtype == torch.uint8 else view.view(weight.dtype)
+
+
 def fp8_amax(input: torch.Tensor) -> torch.Tensor:
     """max|input| as a float32[1] device tensor (no host sync)."""
     inp = _encode_source(input)

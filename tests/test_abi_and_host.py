@@ -297,3 +297,22 @@ def test_automatic_dispatch_table():
     assert pick(512, 4096, 4096, lda=4100) == L.KERNEL_GENERIC                                     # rows not 16-byte aligned
     assert lib.fp8mi_choose_kernel(-1, 1, 1, 1, 1, 1, 0, 0, 0) < 0
 
+
+def test_pad_weight_rows_host_logic():
+    """native.pad_weight_rows is plain tensor bookkeeping (no kernel): values and dtype kept, row stride K + pad, 16-byte row
+    alignment enforced, pad 0 returns the tensor itself."""
+    import sys
+    from conftest import PKG
+    sys.path.insert(0, PKG)
+    import fp8_mi355x_native as native
+    w = torch.randint(0, 255, (6, 8192), dtype=torch.uint8)
+    v = native.pad_weight_rows(w)
+    assert v.shape == w.shape and v.stride() == (8192 + 256, 1) and torch.equal(v, w)
+    v8 = native.pad_weight_rows(w.view(torch.float8_e4m3fn), 512)
+    assert v8.dtype == torch.float8_e4m3fn and v8.stride() == (8192 + 512, 1) and torch.equal(v8.view(torch.uint8), w)
+    assert v8.t().stride() == (1, 8192 + 512)                                  # what the patched torch._scaled_mm receives as `other`
+    assert native.pad_weight_rows(w, 0) is w
+    with pytest.raises(AssertionError):
+        native.pad_weight_rows(w, 100)
+    with pytest.raises(AssertionError):
+        native.pad_weight_rows(torch.zeros(4, 8192))

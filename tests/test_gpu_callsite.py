@@ -141,6 +141,32 @@ def test_plugin_entry_installs_patch_and_flux_linears_match_oracle(cuda, oracle)
     assert not fp8_mps_patch.is_installed()
 
 
+def test_padded_weight_rows_give_the_same_bits_through_both_entry_points(native, cuda, oracle):
+    """native.pad_weight_rows: a weight copied once into rows K + 256 bytes apart (few-token calls against some power-of-two row
+    strides crowd onto a few memory channels: profiles/r03_row_stride.txt).  The stride goes down to the C ABI as `ldb`: same bits as the
+    unpadded call through native.fp8_scaled_mm and through the patched torch._scaled_mm (column-major `other` = padded.t()),
+    for the few-rows, small-tile and large-tile regimes; oracle-checked once."""
+    import fp8_mps_patch
+    rng = np.random.default_rng(808)
+    K, N = 8192, 1024
+    W = torch.from_numpy(rng.integers(0, 120, size=(N, K), dtype=np.uint8)).to(cuda)
+    Wp = native.pad_weight_rows(W)
+    assert Wp.shape == W.shape and Wp.stride() == (K + 256, 1) and torch.equal(Wp, W)
+    s = torch.full((1,), 0.01, device=cuda)
+    fp8_mps_patch.install()
+    try:
+        for M in (1, 4, 16, 64, 300):
+            X = torch.from_numpy(rng.integers(0, 120, size=(M, K), dtype=np.uint8)).to(cuda)
+            a = native.fp8_scaled_mm(X, W, s, s, out_dtype=torch.bfloat16)
+            b = native.fp8_scaled_mm(X, Wp, s, s, out_dtype=torch.bfloat16)
+            assert torch.equal(a, b), M
+            c = torch._scaled_mm(X.view(F8), Wp.view(F8).t(), scale_a=s, scale_b=s, out_dtype=torch.bfloat16)
+            assert torch.equal(a, c), M
+        _check_against_oracle(oracle, b, X, W, None, rng, sa=0.01, sb=0.01)
+    finally:
+        fp8_mps_patch.uninstall()
+
+
 def test_c5_quantize_dequant_at_2_pow_30(native, cuda, oracle):
     """BASELINE config C5 at its stated size.  x = randn * 16, seed 1234."""
     n = 1 << 30
