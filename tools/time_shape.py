@@ -16,14 +16,16 @@ A = torch.randint(0, 120, (M, LD), dtype=torch.uint8, device=dev, generator=g)
 nb = max(2, (320 << 20) // max(N * LD, 1)); nb = min(nb, 24)
 nb = int(os.environ.get("NB", nb))  # NB=1: one weight buffer (cache-resident after the warm-up launches)
 Bs = [torch.randint(0, 120, (N, LD), dtype=torch.uint8, device=dev, generator=g) for _ in range(nb)]
-C = torch.empty(M, N, dtype=torch.float32 if out == "f32" else torch.bfloat16, device=dev)
+PADC = int(os.environ.get("PADC", "0"))  # extra ELEMENTS per row of C (ldc = N + PADC)
+LDC = N + PADC
+C = torch.empty(M, LDC, dtype=torch.float32 if out == "f32" else torch.bfloat16, device=dev)
 s1 = torch.full((1,), 0.01, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 SPLIT = int(os.environ.get("SPLIT", "0"))  # split-K: 0 auto, 1 none, > 1 forced
 ws = torch.zeros(int(lib.fp8mi_scaled_mm_workspace_bytes()), dtype=torch.uint8, device=dev)
 def run(i):
     L.check(lib.fp8mi_scaled_mm_ws(A.data_ptr(), Bs[i % nb].data_ptr(), C.data_ptr(), s1.data_ptr(), s1.data_ptr(), None, None,
-                                   M, N, K, LD, LD, N, 0, 0, 0 if out == "f32" else 2, 0, nan_mode, kid, SPLIT,
+                                   M, N, K, LD, LD, LDC, 0, 0, 0 if out == "f32" else 2, 0, nan_mode, kid, SPLIT,
                                    ws.data_ptr(), ws.numel(), st), "mm")
 for i in range(5): run(i)
 torch.cuda.synchronize()
@@ -31,4 +33,4 @@ with L.kernel_timer(reps) as kt:
     for i in range(reps): run(i)
 torch.cuda.synchronize()
 ms = sorted(kt.ms)
-print(f"M={M} K={K} N={N} pad={PAD} split={SPLIT} kernel={kid} out={out} nan_mode={nan_mode}: avg {sum(ms)/len(ms)*1e3:.2f} us  min {ms[0]*1e3:.2f}  ({2.0*M*N*K/(sum(ms)/len(ms)*1e-3)/1e12:.1f} TFLOP/s)")
+print(f"M={M} K={K} N={N} pad={PAD} padc={PADC} split={SPLIT} kernel={kid} out={out} nan_mode={nan_mode}: avg {sum(ms)/len(ms)*1e3:.2f} us  min {ms[0]*1e3:.2f}  ({2.0*M*N*K/(sum(ms)/len(ms)*1e-3)/1e12:.1f} TFLOP/s)")
