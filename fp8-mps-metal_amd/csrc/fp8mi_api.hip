@@ -279,6 +279,7 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     case FP8MI_KERNEL_GEMM_64x64:
     case FP8MI_KERNEL_GEMM_32x64:
     case FP8MI_KERNEL_GEMM_32x32:
+    case FP8MI_KERNEL_GEMM_128D:
         if (K <= 0 || !fp8mi_gemm_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "MFMA gemm kernel needs K > 0, K %% 16 == 0 and 16-byte aligned rows");
         return hip_result(fp8mi_launch_gemm(p, kernel, s), "gemm");
     case FP8MI_KERNEL_GEMM_256W:

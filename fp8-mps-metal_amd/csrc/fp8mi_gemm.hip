@@ -636,6 +636,8 @@ int fp8mi_choose_gemm_variant(const MMParams &p)
         else if (us256 <= us128 && us256 <= us64) variant = w256 ? FP8MI_KERNEL_GEMM_256W : FP8MI_KERNEL_GEMM_256;
         else if (us128 <= us64) variant = FP8MI_KERNEL_GEMM_128;
         else variant = FP8MI_KERNEL_GEMM_128x64;
+        // more than half a round and at most one round of 128x128 tiles: the deep-ring form of that tile, one workgroup per CU (see fp8mi_launch_gemm)
+        if (t128 > cus / 2 && t128 <= cus) variant = FP8MI_KERNEL_GEMM_128D;   // (from K = 256 on it is the best or tied; a second round is not: M=1088 K=N=4096 41.5 against 29.8 us)
         // Round 3, M = 129 .. 512 (tools/sweep_decode.py with MS=160..512, profiles/r03_mid_m.txt): the fitted model is optimistic about a 128x128 grid
         // that leaves the CUs one workgroup each (its two co-resident workgroups are what hides its prologue / epilogue) - up to two rounds of 128x64
         // tiles are faster (M=512 K=N=8192: 51.7 against 59.5 us; M=256 K=4096 N=14336: 29.6 against 31.8) ...
@@ -665,6 +667,11 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     case FP8MI_KERNEL_GEMM_64x64: return launch<64, 64, 16, 32, 4, 1, 0, 2, 4>(p, s);    // 8 waves of 16x32, 4 x 32 KiB ring, waves 0-3 load
     case FP8MI_KERNEL_GEMM_32x64: return launch<32, 64, 16, 32, 4, 1, 0, 2, 4>(p, s);    // 4 waves of 16x32, 4 x 24 KiB ring
     case FP8MI_KERNEL_GEMM_32x32: return launch<32, 32, 16, 32, 4, 1, 0, 2, 2>(p, s);    // 2 waves of 16x32, 4 x 16 KiB ring: N / 32 tiles need half the K slices (K = N = 8192, M = 32: 14.7 against 18.0 us)
+    // One 128x128 tile per CU at most (end of round 3): the 2 x 32 KiB ring above is built for TWO co-resident workgroups, whose other half hides each one's
+    // single stage in flight; alone on its CU a workgroup waits out a memory round trip per K-step (0.8 us per step).  The same tile on 4 x 32 KiB (three
+    // stages in flight, fragment reads ahead of the stage DMA): M=1024 K=N=4096 21.8 us against 28.1 (128x64, two rounds) / 29.2 (256x128W on half the CUs) /
+    // 31.1 (this tile, shallow ring); M=512 K=N=8192 39.5 against 52.0; M=256 K=4096 N=14336 23.1 against 31.7 (profiles/r03_deep_ring.txt)
+    case FP8MI_KERNEL_GEMM_128D: return launch<128, 128, 64, 32, 4, 1, 0, 1, 4>(p, s);
     case FP8MI_KERNEL_GEMM_256W: return fp8mi_launch_gemm256(p, 0, s);                   // (only chosen above when fp8mi_gemm256_supported)
     case FP8MI_KERNEL_GEMM_256x128W: return fp8mi_launch_gemm256(p, 1000, s);
 #ifdef FP8MI_DIAG  // schedule variants kept for A/B timing (diagnostic library only; same results): tools/ab_kernels.py

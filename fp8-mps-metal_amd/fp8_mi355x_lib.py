@@ -44,6 +44,7 @@ KERNEL_GEMM_256x128W = 21
 KERNEL_GEMM_64x64 = 22
 KERNEL_GEMM_32x64 = 23
 KERNEL_GEMM_32x32 = 24
+KERNEL_GEMM_128D = 25
 WS_COUNTER_BYTES = 4096
 EPILOGUE_TRANSPOSED = 0x100  # OR into bias_dtype (include/fp8mi.h)
 

@@ -81,7 +81,8 @@ enum { FP8MI_KERNEL_AUTO = 0,
        FP8MI_KERNEL_GEMM_256x128W = 21, /* the same on 256x128 tiles (shapes that give 256x256 tiles less than a round) */
        FP8MI_KERNEL_GEMM_64x64 = 22,  /* 64x64x128 tile, 8 waves (33 <= M <= 64 against deep K, and up to M = 128 while the tile grid is small; with split-K) */
        FP8MI_KERNEL_GEMM_32x64 = 23,  /* 32x64x128 tile, 4 waves (9 <= M <= 32: the decode regime; with split-K) */
-       FP8MI_KERNEL_GEMM_32x32 = 24 }; /* 32x32x128 tile, 2 waves (M <= 32 against K, N <= 8192: N / 32 tiles fill the chip with fewer K slices) */
+       FP8MI_KERNEL_GEMM_32x32 = 24,  /* 32x32x128 tile, 2 waves (M <= 32 against K, N <= 8192: N / 32 tiles fill the chip with fewer K slices) */
+       FP8MI_KERNEL_GEMM_128D = 25 }; /* 128x128x128 tile on a DEEP ring (4 x 32 KiB, one workgroup per CU): shapes that give at most one 128x128 tile per CU */
 /* Other ids exist only in the diagnostic build of the library (libfp8mi_diag.so:
  * schedule variants, the producer/consumer kernel and its ablations, kept for
  * A/B timing - tools/README.md); the product library rejects them. */

@@ -286,10 +286,12 @@ def test_automatic_dispatch_table():
     assert pick(2048, 4096, 4096) == L.KERNEL_GEMM_256x128W and pick(4096, 3072, 1536) == L.KERNEL_GEMM_256x128W   # < 1 round of 256x256
     assert pick(64, 8192, 8192) == L.KERNEL_GEMM_32x64 and pick(64, 7168, 7168) == L.KERNEL_GEMM_64x64   # N = 8192: two rows of 32x64 tiles = one whole unsplit round
     # one row of 256x128 tiles on at most half of the CUs streams every B panel unshared: the ring kernel's smaller tiles instead
-    assert pick(192, 4096, 14336) == L.KERNEL_GEMM_128x64 and pick(256, 3072, 12288) == L.KERNEL_GEMM_128x64
+    assert pick(256, 8192, 8192) == L.KERNEL_GEMM_128x64 and pick(192, 4096, 14336) == L.KERNEL_GEMM_128D and pick(256, 3072, 12288) == L.KERNEL_GEMM_128D
     assert pick(256, 4096, 28672) == L.KERNEL_GEMM_256x128W   # ... but not when that one row covers most of the chip
     assert pick(1536, 3072, 4096) == L.KERNEL_GEMM_256x128W                                        # the 8-GPU shard, transposed
-    assert pick(1024, 4096, 4096) == L.KERNEL_GEMM_256x128W and pick(768, 3072, 3072) == L.KERNEL_GEMM_128    # (round 3: 29.3 against 31.2 us on 128x128 tiles; 128x128 keeps small square shapes)
+    # more than half a round, at most one round of 128x128 tiles: that tile on the deep ring, one workgroup per CU (M=1024 K=N=4096: 21.8 against 28.1-31.1 us)
+    assert pick(1024, 4096, 4096) == L.KERNEL_GEMM_128D and pick(768, 3072, 3072) == L.KERNEL_GEMM_128D and pick(512, 8192, 8192) == L.KERNEL_GEMM_128D
+    assert pick(256, 4096, 14336) == L.KERNEL_GEMM_128D and pick(1088, 4096, 4096) == L.KERNEL_GEMM_256x128W and pick(512, 4096, 4096) == L.KERNEL_GEMM_128x64
     assert pick(16384, 1024, 8192) == L.KERNEL_GEMM_256W                                           # shallow K: per-tile fixed cost decides
     assert pick(4096, 3088, 12288) == L.KERNEL_GEMM_256W                                           # K tail: staged with per-lane masks since round 3
     assert pick(4096, 3072, 12292) in (L.KERNEL_GEMM_256, L.KERNEL_GEMM_128)                       # N not a multiple of 8 half columns: a ring kernel

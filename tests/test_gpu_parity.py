@@ -35,7 +35,8 @@ import fp8_mi355x_lib as L  # noqa: E402
 
 # every LDS-tiled MFMA kernel of the product library (the schedule variants and the producer/consumer kernel live in the
 # diagnostic library only: tools/check_kernel.py checks those against the oracle)
-TILE_KERNELS = [L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256, L.KERNEL_GEMM_64x128, L.KERNEL_GEMM_64x64, L.KERNEL_GEMM_32x64, L.KERNEL_GEMM_32x32]
+TILE_KERNELS = [L.KERNEL_GEMM_128, L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_256, L.KERNEL_GEMM_64x128, L.KERNEL_GEMM_64x64, L.KERNEL_GEMM_32x64, L.KERNEL_GEMM_32x32,
+                L.KERNEL_GEMM_128D]
 
 
 def dev(x, cuda, dtype=None):
