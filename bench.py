@@ -19,6 +19,7 @@ Workloads (BASELINE.json configs):
            N dimension is column-sharded over the ranks and the output is
            all-gathered over RCCL/xGMI ("strong" scaling: fixed total work)
   mid      M=2048, K=N=4096, bf16 out  (a mid-size GEMM: one round of 256x128 tiles)
+  wide     M=1024, K=N=4096, fp32 out  (twice C3's rows: one 128x128 tile per CU - the deep-ring class)
   skinny   M=4, K=N=4096               (the reference's batch-4 shape, README.md:77; GB/s)
   gemv_sq  M=1, K=N=14336              (the reference's published big GEMV shape, README.md:77-82)
   quantize / quantize_rne / dequant   2^30 elements   (configs[4]; _rne = torch/OCP rounding through the hardware convert)
@@ -108,7 +109,8 @@ MAX_STREAMS = 4
 # "gemv_sq" = the reference's one published big GEMV shape (test_fp8_metal.py:233-235, README.md:77-82: 2.38 ms on M4 Pro)
 MM_WORKLOADS = {"gemm": (512, 4096, 4096), "gemv": (1, 14336, 4096), "flux": (4096, 3072, 12288),
                 "skinny": (4, 4096, 4096), "decode": (64, 14336, 4096), "gemv_sq": (1, 14336, 14336),
-                "mid": (2048, 4096, 4096)}   # "mid" = one round of 256x128 tiles (the mid-size class between C3 and FLUX)
+                "mid": (2048, 4096, 4096),    # "mid" = one round of 256x128 tiles (the mid-size class between C3 and FLUX)
+                "wide": (1024, 4096, 4096)}   # "wide" = twice C3's rows, fp32 out: one 128x128 tile per CU (FP8MI_KERNEL_GEMM_128D)
 WEIGHT_STREAMING = ("gemv", "skinny", "decode", "gemv_sq")   # quoted in GB/s of algorithmic bytes
 TARGET_STEP_S = 0.016   # a step lasts >= 16 ms: the driver's 20 steps time >= 0.3 s of sustained work per workload
 
@@ -728,7 +730,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="auto", choices=["auto", "gemm", "gemv", "gemv_sq", "flux", "mid", "skinny", "decode", "linear",
+    ap.add_argument("--workload", default="auto", choices=["auto", "gemm", "gemv", "gemv_sq", "flux", "mid", "wide", "skinny", "decode", "linear",
                                                            "quantize", "quantize_rne", "dequant", "callsite"])
     ap.add_argument("--kernel", type=int, default=L.KERNEL_AUTO, help="force an FP8MI_KERNEL_* id")
     ap.add_argument("--nbuf", type=int, default=None, help="override the number of rotating weight buffers "
@@ -825,7 +827,7 @@ def main():
 
     if world == 1 and args.workload == "auto" and not args.no_secondary and not args.force_sharded:
         sec = {}
-        for name in ("gemv", "gemv_sq", "flux", "mid", "skinny", "decode", "linear", "quantize", "quantize_rne", "dequant"):
+        for name in ("gemv", "gemv_sq", "flux", "mid", "wide", "skinny", "decode", "linear", "quantize", "quantize_rne", "dequant"):
             try:
                 r = measure(name, dev, max(3, args.steps // 2), max(1, args.warmup // 2), 1, 0, L.KERNEL_AUTO,
                             with_cpu=(name == "gemv" and not args.no_cpu_baseline), info=info, ceilings=ceilings)
