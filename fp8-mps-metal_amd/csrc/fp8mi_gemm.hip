@@ -645,6 +645,25 @@ int fp8mi_choose_gemm_variant(const MMParams &p)
         // ... and a shallow K on at most one round of 64x64 tiles beats half a round of 128x64 (M=256 K=N=4096: 11.6 against 14.3 us)
         const double t6464 = (double)(((p.M + 63) / 64) * ((p.N + 63) / 64));
         if (variant == FP8MI_KERNEL_GEMM_128x64 && p.M > 128 && p.K <= 4096 && t6464 <= cus && t64 <= cus / 2) variant = FP8MI_KERNEL_GEMM_64x64;
+        // The split-K cliff: 128x64 tiles on 50-60 % of the CUs are too many to split and too few to fill the chip (M=288 K=12288 N=3072, 144 tiles: 34.9 us; M=256,
+        // 96 tiles x 2 slices: 25.3).  One round of 64x64 tiles instead (26.9; K=4096 N=3072 M=288: 10.7 against 14.1), or against a deep K the deep-ring 128x128 tile
+        // (M=384 K=12288 N=3072: 32.0 against 39.5) - profiles/r03_regret.txt
+        if (variant == FP8MI_KERNEL_GEMM_128x64 && p.M > 128 && t64 > cus / 2 && t64 * 5 <= cus * 3) {
+            if (t6464 <= cus) variant = FP8MI_KERNEL_GEMM_64x64;
+            else if (p.K >= 8192) variant = FP8MI_KERNEL_GEMM_128D;
+        }
+        // ... and against a deep K the deep-ring 128x128 tile beats 128x64 tiles that are too many to split even on a quarter of the CUs (M=128 K=N=10240: 29.8 against
+        // 38.8 us; M=192 K=28672 N=6144: 69.1 against 84.2; M=768 K=28672 N=2560: 76.9 against 86.6); at K <= 8192 the 128x64 tile keeps its lead (C3)
+        if (variant == FP8MI_KERNEL_GEMM_128x64 && t64 > cus / 2 && p.K >= 10240 && t128 * 4 >= cus && t128 <= cus) variant = FP8MI_KERNEL_GEMM_128D;
+        // ... unless the last 128-row tile is at most half full and 64x128 tiles fit one round too (M=192 K=N=9216: 25.0 against 39.3 us; M=320 K=3072 N=6144: 14.9 against 17.5;
+        // M=160 K=16384 N=5120: 26.7 against 32.4)
+        // - when that grid is splittable or fills the chip: M=192 K=28672 N=6144, 144 tiles of 64x128 unsplit, 103 us against 69.6)
+        auto fits = [&](double t) { return t <= cus / 2 || (t * 5 >= cus * 4 && t <= cus); };
+        const bool half_tile = ((p.M + 63) / 64) % 2 == 1;   // the last 128-row tile is at most half full
+        if (variant == FP8MI_KERNEL_GEMM_128D && half_tile && fits((double)(((p.M + 63) / 64) * ((p.N + 127) / 128)))) variant = FP8MI_KERNEL_GEMM_64x128;
+        // ... and 128x64 tiles likewise give way to 64x64 (M=160 K=9216 N=1536: 11.0 against 14.2 us; M=160 K=2560 N=5120: 7.9 against 10.1; not N = 4096 against a deep K,
+        // 192 tiles unsplit: M=192 K=14336 32.9 against 27.5)
+        if (variant == FP8MI_KERNEL_GEMM_128x64 && p.M > 128 && half_tile && fits(t6464)) variant = FP8MI_KERNEL_GEMM_64x64;
     }
     return variant;
 }

@@ -267,18 +267,20 @@ def test_automatic_dispatch_table():
         return lib.fp8mi_choose_kernel(M, N, K, lda or K, ldb or K, N, out, ws, split)
 
     assert pick(1, 4096, 4096) == L.KERNEL_GEMV and pick(1, 14336, 4096) == L.KERNEL_GEMV          # configs C1, C2
-    assert pick(4, 4096, 4096) == L.KERNEL_GEMV_MX and pick(2, 4096, 14336) == L.KERNEL_GEMV_MX    # the reference's batch-4 shape
+    assert pick(4, 4096, 4096) == L.KERNEL_GEMV_MX and pick(2, 8192, 5120) == L.KERNEL_GEMV_MX and pick(2, 4096, 14336) == L.KERNEL_GEMM_32x64   # the reference's batch-4 shape; 2 rows against a wide shallow matrix: unsplit 32-row tiles
     assert pick(8, 14336, 4096) == L.KERNEL_GEMM_32x64 and pick(8, 4096, 4096) == L.KERNEL_GEMM_32x32   # 5..8 rows: the small tiles with the K split (round 3)
     assert pick(8, 14336, 4096, ws=0) == L.KERNEL_GEMV_MX and pick(8, 4096, 4096, ws=0) == L.KERNEL_SKINNY   # ... without a workspace: few-rows kernel (deep K) / skinny
     assert pick(4, 14336, 4096) == L.KERNEL_GEMV_MX and pick(64, 5120, 27648) == L.KERNEL_GEMM_64x128   # M <= 4 stays; more than a round of 64-column tiles: 64x128
     assert pick(6, 4096, 14336) == L.KERNEL_GEMM_32x64 and pick(4, 3072, 12288, ws=0) == L.KERNEL_GEMM_32x64   # wide shallow N fills the chip with unsplit 32-row tiles
-    assert pick(4, 2048, 8192) == L.KERNEL_GEMM_32x32 and pick(4, 8192, 8192) == L.KERNEL_GEMV_MX   # ... 32x32 up to N = 8192; deep K and M <= 4 stay on the few-rows kernel
-    assert pick(32, 4096, 4096) == L.KERNEL_GEMM_32x32 and pick(32, 2048, 2048) == L.KERNEL_SKINNY   # small matrices stay on the skinny kernel
+    assert pick(4, 2048, 8192) == L.KERNEL_GEMM_32x32 and pick(4, 8192, 8192) == L.KERNEL_GEMM_32x32 and pick(4, 14336, 4096) == L.KERNEL_GEMV_MX   # ... 32x32 up to N = 8192; 3-4 rows stay on the few-rows kernel only for N < 5120
+    assert pick(32, 4096, 4096) == L.KERNEL_GEMM_32x32 and pick(32, 2048, 2048) == L.KERNEL_GEMM_32x32 and pick(32, 512, 2048) == L.KERNEL_SKINNY   # small matrices too (from 1 MiB and K >= 1024 on); below that the skinny kernel
+    assert pick(8, 7168, 1536) == L.KERNEL_GEMM_32x32 and pick(128, 3072, 2048) == L.KERNEL_GEMM_32x32 and pick(160, 8192, 1024) == L.KERNEL_GEMM_32x64   # the largest small tile that fills the chip, else the smallest that splits
+    assert pick(64, 1024, 12288) == L.KERNEL_GEMM_64x64 and pick(48, 4096, 10240) == L.KERNEL_GEMM_64x64 and pick(48, 3072, 6144) == L.KERNEL_GEMM_32x64
     assert pick(16, 8192, 8192) == L.KERNEL_GEMM_32x32 and pick(64, 4096, 4096) == L.KERNEL_GEMM_32x32   # K, N <= 8192: more tiles, fewer K slices
     assert pick(32, 4096, 4096, ws=0) == L.KERNEL_SKINNY and pick(32, 4096, 4096, split=1) == L.KERNEL_SKINNY   # the small tiles live on the K split
     assert pick(9, 14336, 4096) == L.KERNEL_GEMM_32x64 and pick(24, 12288, 3072) == L.KERNEL_GEMM_32x64       # the decode regime (round 3)
     assert pick(64, 14336, 4096) == L.KERNEL_GEMM_64x64 and pick(64, 14336, 4096, ws=0) == L.KERNEL_GEMM_128x64   # split-K needs the workspace
-    assert pick(48, 4096, 14336) == L.KERNEL_GEMM_64x64 and pick(96, 4096, 4096) == L.KERNEL_GEMM_64x64
+    assert pick(48, 4096, 14336) == L.KERNEL_GEMM_64x64 and pick(96, 4096, 4096) == L.KERNEL_GEMM_32x64 and pick(96, 8192, 4096) == L.KERNEL_GEMM_64x64
     assert pick(96, 4096, 14336) == L.KERNEL_GEMM_128x64 and pick(128, 14336, 4096) == L.KERNEL_GEMM_128x64    # wide N / M > 96 against deep K: 128x64
     assert pick(512, 4096, 4096, out=L.F32) == L.KERNEL_GEMM_128x64                                # config C3
     assert pick(4096, 3072, 12288) == L.KERNEL_GEMM_256W and pick(8192, 8192, 8192) == L.KERNEL_GEMM_256W   # FLUX, 8192^3
@@ -292,6 +294,11 @@ def test_automatic_dispatch_table():
     # more than half a round, at most one round of 128x128 tiles: that tile on the deep ring, one workgroup per CU (M=1024 K=N=4096: 21.8 against 28.1-31.1 us)
     assert pick(1024, 4096, 4096) == L.KERNEL_GEMM_128D and pick(768, 3072, 3072) == L.KERNEL_GEMM_128D and pick(512, 8192, 8192) == L.KERNEL_GEMM_128D
     assert pick(256, 4096, 14336) == L.KERNEL_GEMM_128D and pick(1088, 4096, 4096) == L.KERNEL_GEMM_256x128W and pick(512, 4096, 4096) == L.KERNEL_GEMM_128x64
+    # the cliffs of the K split (end of round 3): tile grids on 50-75 % of the CUs are too many to split and too few to fill the chip
+    assert pick(288, 12288, 3072) == L.KERNEL_GEMM_64x64 and pick(384, 12288, 3072) == L.KERNEL_GEMM_128D and pick(96, 28672, 5120) == L.KERNEL_GEMM_128x64
+    assert pick(64, 14336, 9216) == L.KERNEL_GEMM_64x128 and pick(128, 10240, 10240) == L.KERNEL_GEMM_128D
+    # a last 128-row tile that is at most half full: 64-row tiles when their grid splits or fills the chip
+    assert pick(192, 9216, 9216) == L.KERNEL_GEMM_64x128 and pick(192, 28672, 6144) == L.KERNEL_GEMM_128D and pick(160, 9216, 1536) == L.KERNEL_GEMM_64x64
     assert pick(16384, 1024, 8192) == L.KERNEL_GEMM_256W                                           # shallow K: per-tile fixed cost decides
     assert pick(4096, 3088, 12288) == L.KERNEL_GEMM_256W                                           # K tail: staged with per-lane masks since round 3
     assert pick(4096, 3072, 12292) in (L.KERNEL_GEMM_256, L.KERNEL_GEMM_128)                       # N not a multiple of 8 half columns: a ring kernel

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Random regret sweep: AUTO against every product kernel that accepts the shape, on shapes drawn from LLM / diffusion dimensions.  Prints one line per shape
+and the worst AUTO / best ratios at the end (what the dispatch rules are re-fitted from).
+    [OUT=f32] python tools/sweep_regret.py [seed] [shapes]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "fp8-mps-metal_amd")]
+import numpy as np, torch, fp8_mi355x_lib as L
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+OUT_F32 = os.environ.get("OUT", "bf16") == "f32"
+rng = np.random.default_rng(seed)
+dev = torch.device("cuda:0"); lib = L.load()
+ws = torch.zeros(int(lib.fp8mi_scaled_mm_workspace_bytes()), dtype=torch.uint8, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+s1 = torch.full((1,), 0.01, device=dev)
+g = torch.Generator(device=dev).manual_seed(seed)
+DIMS = [1024, 1536, 2048, 2560, 3072, 4096, 5120, 6144, 7168, 8192, 9216, 10240, 12288, 13824, 14336, 16384, 28672]
+MS = [1, 2, 4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 160, 192, 256, 320, 384, 512, 640, 768, 1024, 1280, 1536, 2048, 3072, 4096, 8192]
+NAMES = {L.KERNEL_GEMV: "gemv", L.KERNEL_GEMV_MX: "mx", L.KERNEL_SKINNY: "skinny", L.KERNEL_GEMM_32x32: "32x32", L.KERNEL_GEMM_32x64: "32x64",
+         L.KERNEL_GEMM_64x64: "64x64", L.KERNEL_GEMM_64x128: "64x128", L.KERNEL_GEMM_128x64: "128x64", L.KERNEL_GEMM_128: "128", L.KERNEL_GEMM_128D: "128D",
+         L.KERNEL_GEMM_256W: "256W", L.KERNEL_GEMM_256x128W: "256x128W"}
+
+
+def candidates(M, K, N):
+    ks = []
+    if M == 1: ks.append(L.KERNEL_GEMV)
+    if 2 <= M <= 8: ks.append(L.KERNEL_GEMV_MX)
+    if 2 <= M <= 64: ks.append(L.KERNEL_SKINNY)
+    if M <= 192: ks += [L.KERNEL_GEMM_32x32, L.KERNEL_GEMM_32x64, L.KERNEL_GEMM_64x64, L.KERNEL_GEMM_64x128]
+    if M > 1: ks += [L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_128]
+    if M > 64 and ((M + 127) // 128) * ((N + 127) // 128) <= 640: ks.append(L.KERNEL_GEMM_128D)
+    if M > 128: ks += [L.KERNEL_GEMM_256x128W]
+    if M > 256: ks += [L.KERNEL_GEMM_256W]
+    return ks
+
+
+rows = []
+done = 0
+while done < count:
+    M, K, N = int(rng.choice(MS)), int(rng.choice(DIMS)), int(rng.choice(DIMS))
+    if 2.0 * M * N * K > 2.5e12 or N * K > (512 << 20): continue
+    done += 1
+    nb = min(16, max(2, (300 << 20) // (N * K)))
+    Bs = [torch.randint(0, 120, (N, K), dtype=torch.uint8, device=dev, generator=g) for _ in range(nb)]
+    A = torch.randint(0, 120, (M, K), dtype=torch.uint8, device=dev, generator=g)
+    C = torch.empty(M, N, dtype=torch.float32 if OUT_F32 else torch.bfloat16, device=dev)
+    res = {}
+    picked = lib.fp8mi_choose_kernel(M, N, K, K, K, N, 0 if OUT_F32 else 2, 1, 0)
+    for kid in [0] + candidates(M, K, N) + [0]:
+        def run(i):
+            return lib.fp8mi_scaled_mm_ws(A.data_ptr(), Bs[i % nb].data_ptr(), C.data_ptr(), s1.data_ptr(), s1.data_ptr(), None, None,
+                                          M, N, K, K, K, N, 0, 0, 0 if OUT_F32 else 2, 0, 0, kid, 0, ws.data_ptr(), ws.numel(), st)
+        if run(0) != 0: continue
+        for i in range(nb + 2): run(i)
+        torch.cuda.synchronize()
+        reps = 16
+        with L.kernel_timer(reps) as kt:
+            for i in range(reps): run(i)
+        torch.cuda.synchronize()
+        ms = sorted(kt.ms); t = ms[len(ms) // 2] * 1e3
+        res[kid] = min(res.get(kid, 1e30), t)   # AUTO is timed first and last: the better of the two
+    best_k, best_t = min(((k, t) for k, t in res.items() if k != 0), key=lambda kv: kv[1])
+    ratio = res[0] / best_t
+    rows.append((ratio, M, K, N, picked, best_k, res[0], best_t))
+    print(f"M={M:5d} K={K:5d} N={N:5d}: auto({NAMES.get(picked, picked)}) {res[0]:7.1f}  " + "  ".join(f"{NAMES[k]} {t:.1f}" for k, t in res.items() if k != 0) +
+          f"   | auto/best {ratio:.2f}", flush=True)
+    del Bs, A, C
+    torch.cuda.empty_cache()
+rows.sort(reverse=True)
+print("# worst 25:")
+for r, M, K, N, pk, bk, ta, tb in rows[:25]:
+    print(f"#  {r:.2f}  M={M} K={K} N={N}: auto = {NAMES.get(pk, pk)} {ta:.1f} us, best = {NAMES[bk]} {tb:.1f} us")
+import statistics
+print(f"# {len(rows)} shapes: median regret {statistics.median(r[0] for r in rows):.3f}, > 1.10: {sum(r[0] > 1.10 for r in rows)}, > 1.20: {sum(r[0] > 1.20 for r in rows)}")
