@@ -120,8 +120,13 @@ static int choose_kernel(const MMParams &p)
             for (int quarters = 3; quarters >= (p.K <= 4096 ? 2 : 3); --quarters) {
                 if (p.M > 32 && fills(t3, quarters)) return FP8MI_KERNEL_GEMM_64x64;
                 if (fills(t2, quarters)) return FP8MI_KERNEL_GEMM_32x64;
-                if (fills(t1, quarters)) return FP8MI_KERNEL_GEMM_32x32;
+                if (fills(t1, quarters) && p.K <= 8192) return FP8MI_KERNEL_GEMM_32x32;   // (against a deeper K the smallest tile's doubled x traffic loses to a split: M=192 K=12288 N=1024 16.3 against 12.3 us)
             }
+            // (deep K: the larger tile first while its slices stay at least 2 KiB deep - M=192 K=12288 N=1024: 64x64 x 5 slices 12.3 us, 32x64 x 2 15.1; but M=64 K=9216 N=1024:
+            //  16 tiles of 64x64 x 16 slices 10.0, 64 of 32x32 x 4 7.6)
+            auto deep_enough = [&](int64_t t) { return t * p.K >= cus * 2048; };
+            if (p.K > 8192 && p.M > 32 && splits(t3) && deep_enough(t3)) return FP8MI_KERNEL_GEMM_64x64;
+            if (p.K > 8192 && splits(t2) && deep_enough(t2)) return FP8MI_KERNEL_GEMM_32x64;
             if (splits(t1)) return FP8MI_KERNEL_GEMM_32x32;
             if (splits(t2)) return FP8MI_KERNEL_GEMM_32x64;
             if (p.M > 128) return FP8MI_KERNEL_GEMM_64x64;
