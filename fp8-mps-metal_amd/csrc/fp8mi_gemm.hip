@@ -662,7 +662,8 @@ int fp8mi_choose_gemm_variant(const MMParams &p)
         // ... unless the last 128-row tile is at most half full and 64x128 tiles fit one round too (M=192 K=N=9216: 25.0 against 39.3 us; M=320 K=3072 N=6144: 14.9 against 17.5;
         // M=160 K=16384 N=5120: 26.7 against 32.4)
         // - when that grid is splittable or fills the chip: M=192 K=28672 N=6144, 144 tiles of 64x128 unsplit, 103 us against 69.6)
-        auto fits = [&](double t) { return t <= cus / 2 || (t * 5 >= cus * 4 && t <= cus); };
+        const bool can_split = p.ws != nullptr && p.split != 1;   // (a sharded linear's calls and callers without a workspace run unsplit: a grid on half the CUs stays there)
+        auto fits = [&](double t) { return (can_split && t <= cus / 2) || (t * 5 >= cus * 4 && t <= cus); };
         const bool half_tile = ((p.M + 63) / 64) % 2 == 1 && p.M <= 320;   // the last 128-row tile is at most half full, of at most three (seven 64-row tiles against four: M=448 K=28672 N=2048 54.0 against 40.8 us)
         if (variant == FP8MI_KERNEL_GEMM_128D && half_tile && fits((double)(((p.M + 63) / 64) * ((p.N + 127) / 128)))) variant = FP8MI_KERNEL_GEMM_64x128;
         // ... and 128x64 tiles likewise give way to 64x64 (M=160 K=9216 N=1536: 11.0 against 14.2 us; M=160 K=2560 N=5120: 7.9 against 10.1; not N = 4096 against a deep K,
@@ -671,7 +672,7 @@ int fp8mi_choose_gemm_variant(const MMParams &p)
         //  workgroups x slices fill the chip as well as the other's: M=192 K=28672 N=2048, 96 x 2 against 64 x 4, 35.5 against 27.4; M=160 K=16384 N=1024, 48 x 5 against 32 x 8, 12.3 against 15.7)
         auto filled = [&](double t) { const double sl = (double)(int64_t)(cus / t); return t * (sl > 16 ? 16 : sl); };
         if (variant == FP8MI_KERNEL_GEMM_128x64 && p.M > 128 && p.M <= 192 &&
-            (t6464 > cus / 2 ? fits(t6464) : (t64 <= cus / 2 && filled(t6464) * 10 >= filled(t64) * 9))) variant = FP8MI_KERNEL_GEMM_64x64;
+            (t6464 > cus / 2 ? fits(t6464) : (can_split && t64 <= cus / 2 && filled(t6464) * 10 >= filled(t64) * 9))) variant = FP8MI_KERNEL_GEMM_64x64;
     }
     return variant;
 }
