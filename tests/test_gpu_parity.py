@@ -622,6 +622,31 @@ def test_gemm256w_parity_and_bits_of_the_ring_kernel(native, cuda, oracle, M, K,
     assert nan[min(3, M - 1), :].all() and nan[:, N - 1].all() and nan.sum() == N + M - 1
 
 
+@pytest.mark.parametrize("M,K,N", [(512, 1024, 384), (300, 640, 264), (129, 3072, 72), (1024, 512, 256)])
+def test_every_unsplit_tile_kernel_gives_the_same_bits(native, cuda, oracle, M, K, N):
+    """What the sharded linear's bit equality rests on: whichever tile kernel a shape - or its transposed shard - lands on, an UNSPLIT tile kernel adds the
+    K-steps of an output element in the same order, so all of them (ring kernels of every tile shape, the deep-ring 128x128, the small-batch tiles, both one-wave-per-SIMD
+    forms) return identical bits for identical inputs and epilogues; one of them is checked against the oracle."""
+    rng = np.random.default_rng(M + 3 * K + N)
+    A = clean_bytes(rng, (M, K))
+    B = clean_bytes(rng, (N, K))
+    sa = rng.uniform(0.005, 0.02, size=M).astype(np.float32)
+    sb = rng.uniform(0.005, 0.02, size=N).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    tA, tB, tsa, tsb, tb = dev(A, cuda), dev(B, cuda), dev(sa, cuda), dev(sb, cuda), dev(bias, cuda)
+    check_mm(oracle, native, cuda, A, B, sa, sb, kernel=L.KERNEL_GEMM_128D, bias=bias)
+    kernels = list(TILE_KERNELS) + [L.KERNEL_GEMM_256W, L.KERNEL_GEMM_256x128W]
+    for od in (torch.float32, torch.bfloat16):
+        ref = None
+        for kern in kernels:
+            got = native.fp8_scaled_mm(tA, tB, tsa, tsb, bias=tb, out_dtype=od, kernel=kern, split_k=1)
+            if ref is None:
+                ref = got
+            assert torch.equal(got, ref), (kern, od)
+        auto = native.fp8_scaled_mm(tA, tB, tsa, tsb, bias=tb, out_dtype=od, split_k=1)   # AUTO without a K split: one of them
+        assert torch.equal(auto, ref), od
+
+
 @pytest.mark.parametrize("wk", [L.KERNEL_GEMM_256W, L.KERNEL_GEMM_256x128W])
 def test_gemm256w_random_shapes(native, cuda, oracle, wk):
     """Seeded random shapes inside the kernel's envelope (any M, N a multiple of 8, K a multiple of 128) with random
