@@ -134,8 +134,7 @@ static int choose_kernel(const MMParams &p)
         // ... and 32x32 tiles where K and N stay within 8192: twice the tiles = half the K slices (none at N = 8192), the partial exchange being what the
         // regime pays for (K=N=8192 M=32: 14.7 against 18.0 us; K=N=4096: 7.2 against 8.1); against a deeper K their doubled x traffic loses (K=12288 N=3072: 12.3 against 11.6)
         if (p.M <= 32) return ((p.N <= 8192 && p.K <= 8192) || p.N <= 2048) ? FP8MI_KERNEL_GEMM_32x32 : FP8MI_KERNEL_GEMM_32x64;   // (a narrow N at any K: M=16 K=14336 N=1536 9.1 against 10.5 us)
-        if (p.M <= 64 && (double)p.N * (double)p.K <= 16.0 * 1048576.0 && ((p.M + 31) / 32) * ((p.N + 31) / 32) <= 2 * cus) return FP8MI_KERNEL_GEMM_32x32;   // (at most two rounds: M=64 K=1024 N=16384, 1024 tiles, 7.9 against 5.5 us on 64x64)
-          // (K=N=4096, M=48-64: 7.6 against 9.4 us on 64x64)
+        if (p.M <= 64 && (double)p.N * (double)p.K <= 16.0 * 1048576.0 && ((p.M + 31) / 32) * ((p.N + 31) / 32) <= 2 * cus) return FP8MI_KERNEL_GEMM_32x32;   // (K=N=4096, M=48-64: 7.6 against 9.4 us on 64x64; at most two rounds: M=64 K=1024 N=16384, 1024 tiles, 7.9 against 5.5)
         // (33..64 rows against N = 8192-ish: two rows of 32x64 tiles are one whole round with NO K split, i.e. no partial exchange, where 64x64 tiles need
         //  2 slices - K=N=8192 M=33 / 48 / 64: 15.7 / 17.4 / 18.0 against 19.3 / 19.2 / 19.1 us, K=4096 9.4-10.5 against 10.4-10.8; at N = 7936, 248 tiles, 64x64 x 2 is 6 % ahead again and stays)
         if (p.M <= 64 && p.K <= 8192 && 2 * ((p.N + 63) / 64) <= cus && 2 * ((p.N + 63) / 64) > cus - 4) return FP8MI_KERNEL_GEMM_32x64;
