@@ -272,32 +272,55 @@ class stdout_to_stderr:
         return False
 
 
-def capture_sharded(w, dev):
+def agree_on_graph(ok, graph, replay, flag_device):
+    """Every rank must take the same branch: a rank whose capture failed must not sit in an all-reduce while the others replay a graph
+    full of all-gathers (a deadlock, not an error).  So NOTHING captured is replayed before the ranks have agreed: all-reduce(MIN) of the
+    local verdict first, then the first replay on every rank or on none.  `replay` runs (and synchronises) the local graph once; a failure
+    of that first replay is a second, equally agreed, verdict.  Returns the graph or None - the same on every rank."""
+    def all_ok(v):
+        t = torch.tensor([1 if v else 0], dtype=torch.int32, device=flag_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+    if not all_ok(ok and graph is not None):
+        return None
+    ok2 = True
+    try:
+        replay(graph)
+    except Exception as e:
+        ok2 = False
+        log(f"[bench] first replay of the captured sharded step failed ({e!r}); running it eagerly")
+    return graph if all_ok(ok2) else None
+
+
+def capture_sharded(w, dev, inject_failure=False):
     """The sharded step (per linear: `chunks` GEMM launches + `chunks` in-place all-gathers on a side stream) as ONE HIP graph: eagerly the host
     needs ~80 us per linear for the launches, events and collectives (1-rank rehearsal: 197 us per FLUX linear against 120 us of kernel), which at
     N = 8 - shard GEMMs of ~12 us per chunk - would be the critical path.  RCCL collectives capture into HIP graphs (tested with one rank:
-    tests/test_gpu_patch.py); every rank must take the same branch, so success is agreed on with an all-reduce before the graph is used."""
-    ok, graph = 1, None
+    tests/test_gpu_patch.py).  The warm-up steps run real collectives on every rank (a failure there is fatal for the job, as for any eager step);
+    the capture only RECORDS; the captured collectives first run after agree_on_graph()."""
+    cur = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        w.step(None)   # warm: communicator, the module's side stream and events, allocator
+        w.step(None)
+    cur.wait_stream(side)
+    torch.cuda.synchronize(dev)
+    ok, graph = True, None
     try:
-        cur = torch.cuda.current_stream(dev)
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            w.step(None)   # warm: communicator, the module's side stream and events, allocator
-            w.step(None)
-        cur.wait_stream(side)
-        torch.cuda.synchronize(dev)
+        if inject_failure:
+            raise RuntimeError("injected capture failure")
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             w.step(None)
-        graph.replay()
-        torch.cuda.synchronize(dev)
     except Exception as e:   # capture not possible here: every rank falls back to eager steps
-        ok = 0
+        ok, graph = False, None
         log(f"[bench] sharded step not captured ({e!r}); running it eagerly")
-    t = torch.tensor([ok], dtype=torch.int32, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return graph if int(t.item()) == 1 else None
+
+    def first_replay(g):
+        g.replay()
+        torch.cuda.synchronize(dev)
+    return agree_on_graph(ok, graph, first_replay, dev)
 
 
 def time_steps(w, steps, warmup, use_graph, world, n_streams=1):
@@ -377,6 +400,7 @@ def kernel_durations(w, launches):
 
 
 _PROBE = None
+PROBE_ABI = 2   # tools/ceiling_probe.hip probe_abi_version(): 2 = probe_read takes (buf, sink, bytes, blocks, in_flight, stream)
 
 
 def _probe_lib():
@@ -389,7 +413,18 @@ def _probe_lib():
         # and tools/profile_round.sh build it; a missing probe is reported, not repaired.
         if not os.path.exists(so):
             raise RuntimeError("tools/libceiling_probe.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+        src = os.path.join(ROOT, "tools", "ceiling_probe.hip")
+        if os.path.exists(src) and os.path.getmtime(so) < os.path.getmtime(src):
+            # a probe left over from an older source has another C signature: calling it would hand it an int as its stream
+            raise RuntimeError("tools/libceiling_probe.so is older than tools/ceiling_probe.hip: rebuild it (__graft_entry__.build())")
         lib = ctypes.CDLL(so)
+        try:   # the probe states its own ABI revision; bench.py and the probe must agree (a stale .so with a fresh mtime is refused too)
+            lib.probe_abi_version.restype = ctypes.c_int
+            abi = int(lib.probe_abi_version())
+        except AttributeError:
+            abi = -1
+        if abi != PROBE_ABI:
+            raise RuntimeError(f"tools/libceiling_probe.so has probe ABI {abi}, bench.py expects {PROBE_ABI}: rebuild it")
         vp = ctypes.c_void_p
         lib.probe_mfma.restype = ctypes.c_int
         lib.probe_mfma.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
@@ -725,6 +760,82 @@ def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info, nbuf=
     return res
 
 
+def self_launch(n, argv, dry=False):
+    """Start `python -m torch.distributed.run --nproc-per-node n bench.py <argv>` as a child process: what the driver's N > 1 command line
+    is, for callers that run plain `python bench.py --gpus N`.  Rendezvous on 127.0.0.1 (the container hostname may not resolve), a free
+    port, the environment unchanged apart from HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC: RCCL's peer mappings need it on this pool).
+    stdout of the children is filtered down to rank 0's ONE JSON line; everything else they print goes to stderr."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    if dry:
+        print(json.dumps({"launch": cmd, "ranks": n, "env": {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log(f"[bench] --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.lstrip().startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        log("[bench] the ranks exited cleanly but printed no bench line")
+        rc = 1
+    return rc
+
+
+def rccl_report(dev, world, backend, debug_file):
+    """What the communicator actually is (N > 1): ranks the backend sees after the warm-up all-reduce, the devices behind them, and the
+    transport / algorithm lines of RCCL's own bring-up log (NCCL_DEBUG=INFO into a per-process file, parsed by rank 0)."""
+    rep = {"backend": backend, "rccl_ranks": dist.get_world_size()}
+    try:
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": dist.get_rank(), "device_index": dev.index, "uuid": str(getattr(props, "uuid", "n/a")),
+                "pci": f"{getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', 0):02x}:{getattr(props, 'pci_device_id', 0):02x}"}
+        allp = [None] * world
+        dist.all_gather_object(allp, mine)
+        rep["devices"] = allp
+        rep["device_uuids"] = [d["uuid"] for d in allp]
+        rep["distinct_devices"] = len({(d["uuid"], d["pci"]) for d in allp})
+    except Exception as e:
+        rep["devices_error"] = repr(e)
+    try:
+        if debug_file and os.path.exists(debug_file):
+            rep["nccl_debug"] = parse_nccl_debug(open(debug_file, errors="replace").read())
+    except Exception as e:
+        rep["nccl_debug_error"] = repr(e)
+    return rep
+
+
+def parse_nccl_debug(text):
+    """Summary of an NCCL_DEBUG=INFO log: version, transports by kind (`via P2P/...`, `via SHM`, `via NET/...`), channel counts,
+    the ring / tree lines of the topology search and any algorithm / protocol choice RCCL printed."""
+    import re
+    out = {"transports": {}, "lines": 0}
+    keep = []
+    for ln in text.splitlines():
+        out["lines"] += 1
+        m = re.search(r"via (P2P/[A-Za-z_/]+|SHM[/A-Za-z_]*|NET/[A-Za-z0-9_/]+|direct[ A-Za-z]*)", ln)
+        if m:
+            k = m.group(1).strip()
+            out["transports"][k] = out["transports"].get(k, 0) + 1
+        if re.search(r"(RCCL version|NCCL version|nranks|[0-9]+ coll channels|Connected all (rings|trees)|Ring [0-9]+ :|Trees? \[|"
+                     r"Algo|Proto|xgmi|XGMI|nNodes|comm 0x[0-9a-f]+ rank .* Init COMPLETE)", ln) and len(keep) < 24:
+            keep.append(ln.strip()[-220:])
+    out["selected_lines"] = keep
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -745,9 +856,19 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearse the multi-GPU code path (sharded linear + RCCL all-gather) with a 1-rank group")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="with --gpus N > 1 and no WORLD_SIZE: print the torch.distributed.run command bench.py would start, as JSON, and exit")
     args = ap.parse_args()
     global DATA_MODE
     DATA_MODE = args.data
+
+    # `python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks HERE (one process per GPU over RCCL), before
+    # anything has touched the GPU (a child process, never an exec), pass rank 0's line through and exit with the child's code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, [a for a in sys.argv[1:] if a != "--dry-launch"], dry=args.dry_launch))
+    if args.dry_launch:
+        print(json.dumps({"launch": None, "note": "nothing to launch: --gpus 1, or WORLD_SIZE is set (a launcher is already around bench.py)"}))
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -763,13 +884,25 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        nccl_debug_file = None
+        if backend == "nccl" and "NCCL_DEBUG" not in os.environ:
+            # RCCL's own account of the communicator (transports, channels, rings) into a per-process file that rank 0 parses onto the line
+            import tempfile
+            nccl_debug_file = os.path.join(tempfile.gettempdir(), f"fp8mi_bench_nccl_{os.getpid()}.log")
+            os.environ["NCCL_DEBUG"] = "INFO"
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,ENV,TUNING")
+            os.environ["NCCL_DEBUG_FILE"] = nccl_debug_file
         with stdout_to_stderr():   # (RCCL's version banner goes to stdout when the communicator comes up)
             dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
             t0 = torch.zeros(1, device=dev)
             dist.all_reduce(t0)    # forces the communicator (and its banner) now
             torch.cuda.synchronize(dev)
+            comm_report = rccl_report(dev, world, backend, nccl_debug_file)
+            comm_report["warmup_allreduce_sum"] = float(t0.item())   # = 0: the collective ran over every rank and returned
+    else:
+        comm_report = None
     if args.gpus != world and rank == 0:
-        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world} (set by the launcher around bench.py); using WORLD_SIZE")
     L.load()
     info = L.device_info(dev.index)
 
@@ -818,6 +951,10 @@ def main():
     }
     if "allgather_only" in res:
         line["allgather_only"] = res["allgather_only"]
+    if comm_report is not None:
+        line["communicator"] = comm_report
+        line["rccl_ranks"] = comm_report.get("rccl_ranks")
+        line["device_uuids"] = comm_report.get("device_uuids")
     if same_workload_1gpu is not None:
         line["same_workload_on_one_gpu"] = same_workload_1gpu
     if "cpu_baseline" in res:

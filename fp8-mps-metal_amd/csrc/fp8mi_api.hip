@@ -77,7 +77,7 @@ int fp8mi_cu_count()
 static int choose_kernel(const MMParams &p)
 {
     if (fp8mi_gemv_supported(p)) return FP8MI_KERNEL_GEMV;
-    if (p.M >= 2 && p.M <= 8 && p.K <= 6144 && fp8mi_gemm_supported(p) && (p.N + 63) / 64 >= fp8mi_cu_count() / 2) {   // (M = 2 since the regret sweep: K=1024 N=16384 5.3 against 9.3 us, K=2048 N=13824 7.3 against 8.8)
+    if (p.M >= 2 && p.M <= 8 && p.K > 0 && p.K <= 6144 && fp8mi_gemm_supported(p) && (p.N + 63) / 64 >= fp8mi_cu_count() / 2) {   // (M = 2 since the regret sweep: K=1024 N=16384 5.3 against 9.3 us, K=2048 N=13824 7.3 against 8.8)
         // a few rows against a WIDE, shallow weight matrix: N alone fills the chip with unsplit 32-row tiles, which stream W through the LDS-DMA ring
         // while the few-rows kernel re-reads x per group of weight rows (round 3, tools/time_shape.py: M=4 K=4096 N=14336 12.1 against 14.6 us,
         // M=8 11.9 against 14.8; M=4 K=3072 N=12288 8.8 against 12.1; M=8 K=4096 N=8192 9.8 against 13.0; M=2: equal, stays below); up to N = 8192 the
@@ -238,8 +238,10 @@ int fp8mi_device_info(int device, fp8mi_device_info_t *out)
 
 int64_t fp8mi_scaled_mm_workspace_bytes(void)
 {
-    // the library only splits on its own when tiles * slices <= 256 workgroups of a 128x64 (or 64x128) tile:
-    // 256 x 32 KiB of fp32 partials + the counters; twice that leaves room for forced splits
+    // counters + room for the fp32 partial tiles of every split the library takes on its own, on any of the split-capable ring tiles
+    // (128x64 / 64x128: 32 KiB per workgroup; 64x64 16 KiB, 32x64 8 KiB, 32x32 4 KiB; 128x128 64 KiB): tiles x slices stays within one
+    // workgroup per CU, 256 x 32 KiB at most; twice that leaves room for forced splits (split_k > 0).  A split whose partials do not fit
+    // the caller's workspace is refused by the launcher (fp8mi_gemm.hip), never truncated.
     return (int64_t)FP8MI_WS_COUNTER_BYTES + 2 * 256 * (int64_t)(128 * 64 * 4);
 }
 

@@ -73,6 +73,29 @@ static int run_mm(int M, int K, int N, double tol, int split_k)
     return worst <= tol ? 0 : 1;
 }
 
+/* K = 0 against a wide N through the workspace entry point with 16-byte "strides" (ADVICE r3): the automatic dispatch must not hand the
+   problem to a tile kernel that refuses K = 0 - the result is the empty sum, 0 (no bias here), from the generic kernel */
+static int run_k0(void)
+{
+    const int M = 4, N = 16384;
+    float *dC, *dsa, *dsb, one = 1.0f;
+    CHECK_HIP(hipMalloc((void **)&dC, sizeof(float) * M * N)); CHECK_HIP(hipMemset(dC, 0x5A, sizeof(float) * M * N));
+    CHECK_HIP(hipMalloc((void **)&dsa, 4)); CHECK_HIP(hipMalloc((void **)&dsb, 4));
+    CHECK_HIP(hipMemcpy(dsa, &one, 4, hipMemcpyHostToDevice)); CHECK_HIP(hipMemcpy(dsb, &one, 4, hipMemcpyHostToDevice));
+    void *ws; int64_t ws_bytes = fp8mi_scaled_mm_workspace_bytes();
+    CHECK_HIP(hipMalloc(&ws, (size_t)ws_bytes)); CHECK_HIP(hipMemset(ws, 0, FP8MI_WS_COUNTER_BYTES));
+    if (fp8mi_choose_kernel(M, N, 0, 16, 16, N, FP8MI_F32, 1, 0) != FP8MI_KERNEL_GENERIC) { printf("K = 0: AUTO does not pick the generic kernel\n"); return 1; }
+    CHECK_MI(fp8mi_scaled_mm_ws(NULL, NULL, dC, dsa, dsb, NULL, NULL, M, N, 0, 16, 16, N, FP8MI_SCALE_TENSOR, FP8MI_SCALE_TENSOR, FP8MI_F32, 0,
+                                FP8MI_NAN_ZERO, FP8MI_KERNEL_AUTO, 0, ws, ws_bytes, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    float *C = malloc(sizeof(float) * M * N);
+    CHECK_HIP(hipMemcpy(C, dC, sizeof(float) * M * N, hipMemcpyDeviceToHost));
+    for (int i = 0; i < M * N; ++i) if (C[i] != 0.0f) { printf("K = 0: C[%d] = %g, expected 0\n", i, C[i]); return 1; }
+    printf("scaled_mm K=0 M=%d N=%d through fp8mi_scaled_mm_ws: all zero\n", M, N);
+    hipFree(dC); hipFree(dsa); hipFree(dsb); hipFree(ws); free(C);
+    return 0;
+}
+
 int main(void)
 {
     printf("libfp8mi version %#x\n", fp8mi_version());
@@ -117,6 +140,7 @@ int main(void)
     rc |= run_mm(3, 100, 7, 4e-6, 1);        /* generic (K % 16 != 0) */
     rc |= run_mm(96, 4096, 200, 1e-3, 0);    /* tile GEMM, split-K chosen by the library, host-owned workspace */
     rc |= run_mm(40, 2064, 130, 1e-3, 3);    /* forced 3 slices, K tail in the last one */
+    rc |= run_k0();
     printf(rc ? "FAILED\n" : "C ABI round trip: ok\n");
     return rc;
 }

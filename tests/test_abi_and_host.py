@@ -304,6 +304,7 @@ def test_automatic_dispatch_table():
     assert pick(4096, 3072, 12292) in (L.KERNEL_GEMM_256, L.KERNEL_GEMM_128)                       # N not a multiple of 8 half columns: a ring kernel
     assert pick(5, 100, 7) == L.KERNEL_GENERIC                                                     # K % 16 != 0
     assert pick(512, 4096, 4096, lda=4100) == L.KERNEL_GENERIC                                     # rows not 16-byte aligned
+    assert pick(4, 0, 16384, lda=16, ldb=16) == L.KERNEL_GENERIC and pick(512, 0, 4096, lda=16, ldb=16) == L.KERNEL_GENERIC   # K = 0: the empty sum (bias only), never a tile kernel
     assert lib.fp8mi_choose_kernel(-1, 1, 1, 1, 1, 1, 0, 0, 0) < 0
 
 

