@@ -528,6 +528,66 @@ def roofline_of(w, kd, info, traffic_and_source, ceilings=None):
     return r
 
 
+FLOOR_IDS = {"gemm": (901, 902, 903), "wide": (911, 912, 913)}   # tools/floor_probe.hip: (DMA stream only, launch + C store only, launch only)
+FLOOR_PROBE_ABI = 1
+
+
+def measure_floor(w, launches=128):
+    """`roofline.floor`: what ONE dispatch of this workload's kernel costs on this box before it multiplies anything - timing-only forms of the
+    SAME kernel source (tools/floor_probe.hip compiles fp8mi_gemm.hip with FP8MI_FLOOR_PROBE), timed like the real kernel: per-dispatch
+    start/stop events, rotating weight buffers, untimed burst first, the lower of two pass averages.
+      empty_launch_us   the kernel returns behind its argument loads (same grid, block and LDS allocation)
+      c_store_only_us   no K loop: launch, arguments, tile map, the fused epilogue's store of the whole C, kernel end
+      dma_only_us       the K loop's LDS-DMA stream with its waits and barriers, no fragment reads, no MFMAs (+ everything above)
+    The real kernel hides its MFMAs and fragment reads under that stream, so dma_only_us is this design's attainable floor."""
+    if w.name not in FLOOR_IDS or w.sharded:
+        return None
+    try:
+        so = os.path.join(ROOT, "tools", "libfloor_probe.so")
+        src = os.path.join(ROOT, "tools", "floor_probe.hip")
+        if not os.path.exists(so):
+            return {"error": "tools/libfloor_probe.so not built (python -c 'import __graft_entry__ as g; g.build()')"}
+        newest = max(os.path.getmtime(f) for f in [src] + [os.path.join(PKG, "csrc", n) for n in ("fp8mi_gemm.hip", "fp8mi_gemm_epi.h", "fp8mi_common.h")])
+        if os.path.getmtime(so) < newest:
+            return {"error": "tools/libfloor_probe.so is older than the kernel sources it compiles: rebuild it (__graft_entry__.build())"}
+        lib = ctypes.CDLL(so)
+        lib.floor_probe_abi_version.restype = ctypes.c_int
+        if int(lib.floor_probe_abi_version()) != FLOOR_PROBE_ABI:
+            return {"error": "tools/libfloor_probe.so has another probe ABI: rebuild it"}
+        vp = ctypes.c_void_p
+        lib.floor_probe_run.restype = ctypes.c_int
+        lib.floor_probe_run.argtypes = [ctypes.c_int, vp, ctypes.POINTER(vp), ctypes.c_int, vp, vp, vp, ctypes.c_longlong, ctypes.c_longlong,
+                                        ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
+        nb = len(w.Bs)
+        Bs = (vp * nb)(*[b.data_ptr() for b in w.Bs])
+        st = torch.cuda.current_stream(w.dev).cuda_stream
+        out = (ctypes.c_float * launches)()
+
+        def avg_us(kid):
+            best = None
+            for _ in range(2):
+                rc = lib.floor_probe_run(kid, w.A.data_ptr(), Bs, nb, w.Cs[0].data_ptr(), w.sa.data_ptr(), w.sb.data_ptr(), w.M, w.N, w.K,
+                                         w.code, min(launches, 64), st, out)   # untimed burst (clocks up)
+                if rc:
+                    raise RuntimeError(f"floor_probe_run({kid}) -> {rc}")
+                rc = lib.floor_probe_run(kid, w.A.data_ptr(), Bs, nb, w.Cs[0].data_ptr(), w.sa.data_ptr(), w.sb.data_ptr(), w.M, w.N, w.K,
+                                         w.code, launches, st, out)
+                if rc:
+                    raise RuntimeError(f"floor_probe_run({kid}) -> {rc}")
+                a = sum(out[i] for i in range(launches)) / launches * 1e3
+                best = a if best is None or a < best else best
+            return round(best, 3)
+        dma, store, empty = FLOOR_IDS[w.name]
+        res = {"empty_launch_us": avg_us(empty), "c_store_only_us": avg_us(store), "dma_only_us": avg_us(dma),
+               "method": "timing-only forms of the same kernel source (tools/floor_probe.hip, Cfg::FLOOR), per-dispatch events, "
+                         f"{launches} launches over the workload's rotating weight buffers, lower of two pass averages",
+               "launches_timed": launches}
+        torch.cuda.synchronize(w.dev)
+        return res
+    except Exception as e:   # context, never a reason to lose the bench line
+        return {"error": repr(e)}
+
+
 def cpu_baseline(w, budget_s=12.0):
     """The C oracle (OpenMP) on the host cores, bounded sample of the same workload."""
     so = os.path.join(ORACLE, "libfp8_oracle.so")
@@ -751,6 +811,13 @@ def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info, nbuf=
     res = {"value": round(value, 3), "unit": unit, "ms_per_step": round(dt / steps * 1e3, 5),
            "launches_per_step": w.inner, "hip_graph": graphed, "streams": n_streams, "dtype": dtype_of(name), "config": w.desc,
            "roofline": roofline_of(w, kd, info, load_traffic(name) if world == 1 and not w.sharded else None, ceilings)}
+    if res["roofline"] is not None and world == 1 and kernel == L.KERNEL_AUTO:
+        fl = measure_floor(w)
+        if fl is not None:
+            if "dma_only_us" in fl and res["roofline"].get("kernel_avg_us"):
+                fl["kernel_over_dma_only"] = round(res["roofline"]["kernel_avg_us"] / fl["dma_only_us"], 3)
+                fl["frac_at_dma_only"] = round(res["roofline"]["frac"] * res["roofline"]["kernel_avg_us"] / fl["dma_only_us"], 4)   # the roofline fraction this design would read if the kernel ran in dma_only_us
+            res["roofline"]["floor"] = fl
     if w.sharded and dist.is_initialized():
         res["allgather_only"] = allgather_only(w)   # GEMM-only rate is roofline.achieved, this is the collective
     if with_cpu:
@@ -836,6 +903,37 @@ def parse_nccl_debug(text):
     return out
 
 
+def under_profiler():
+    """rocprofv3 preloads a library that initialises the GPU before Python starts; a child process started from here would be an exec behind a
+    GPU-initialising preload, which this pool forbids."""
+    env = os.environ
+    return any("rocprof" in env.get(k, "").lower() for k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIB")) or any(k.startswith("ROCPROF") for k in env)
+
+
+def host_kernarg_child(steps, warmup):
+    """`secondary.gemm_host_kernarg`: the headline workload (C3) as a process that does NOT set HIP_FORCE_DEV_KERNARG runs it - what a ComfyUI
+    plugin gets, since the knob has to be in the environment before libamdhip64 loads and a plugin is imported long after.
+    A fresh child process, started and finished BEFORE this process touches the GPU (no exec behind an initialised GPU, no two benches at once)."""
+    import subprocess
+    env = dict(os.environ, HIP_FORCE_DEV_KERNARG="0", FP8MI_BENCH_CHILD="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "gemm", "--steps", str(max(3, steps // 2)), "--warmup", str(max(1, warmup // 2)),
+           "--no-secondary", "--no-cpu-baseline", "--no-ceilings"]
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        for ln in reversed(out.stdout.splitlines()):
+            if ln.lstrip().startswith('{"metric"'):
+                d = json.loads(ln)
+                r = d.get("roofline") or {}
+                return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dev_kernarg": d["config"].get("dev_kernarg"),
+                        "kernel_avg_us": r.get("kernel_avg_us"), "kernel_min_us": r.get("kernel_min_us"), "frac": r.get("frac"),
+                        "launches_per_step": d["config"].get("launches_per_step"), "config": {"workload": d["config"].get("workload")},
+                        "note": "same workload and binary as the headline, kernel arguments in HOST memory (HIP_FORCE_DEV_KERNARG=0: the HIP "
+                                "runtime's default); run in a child process before this one initialised the GPU"}
+        return {"error": f"child printed no bench line (rc {out.returncode}): {out.stderr[-300:]}"}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -854,6 +952,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ceilings", action="store_true", help="skip the in-run MFMA / streaming-read ceiling probes")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-host-kernarg", action="store_true", help="skip secondary.gemm_host_kernarg (a child process that runs C3 with kernel arguments in host memory)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearse the multi-GPU code path (sharded linear + RCCL all-gather) with a 1-rank group")
     ap.add_argument("--dry-launch", action="store_true",
@@ -872,6 +971,10 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    host_kernarg = None
+    if (world == 1 and args.workload == "auto" and not args.no_secondary and not args.force_sharded and not args.no_host_kernarg
+            and os.environ.get("FP8MI_BENCH_CHILD") != "1" and os.environ.get("HIP_FORCE_DEV_KERNARG") == "1"):
+        host_kernarg = {"skipped": "under a profiler preload: no child processes"} if under_profiler() else host_kernarg_child(args.steps, args.warmup)
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the product has no CPU path")
@@ -977,6 +1080,8 @@ def main():
             sec["callsite_eager"] = callsite_eager(dev, info)
         except Exception as e:
             sec["callsite_eager"] = {"error": repr(e)}
+        if host_kernarg is not None:
+            sec["gemm_host_kernarg"] = host_kernarg
         line["secondary"] = sec
 
     if rank == 0:

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <vector>
 
 #include "fp8mi_common.h"
@@ -241,7 +242,7 @@ int64_t fp8mi_scaled_mm_workspace_bytes(void)
     // counters + room for the fp32 partial tiles of every split the library takes on its own, on any of the split-capable ring tiles
     // (128x64 / 64x128: 32 KiB per workgroup; 64x64 16 KiB, 32x64 8 KiB, 32x32 4 KiB; 128x128 64 KiB): tiles x slices stays within one
     // workgroup per CU, 256 x 32 KiB at most; twice that leaves room for forced splits (split_k > 0).  A split whose partials do not fit
-    // the caller's workspace is refused by the launcher (fp8mi_gemm.hip), never truncated.
+    // the caller's workspace is clamped to the largest slice count that does (resolve_split, fp8mi_gemm_epi.h).
     return (int64_t)FP8MI_WS_COUNTER_BYTES + 2 * 256 * (int64_t)(128 * 64 * 4);
 }
 
@@ -303,7 +304,24 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     p.ws_bytes = workspace ? workspace_bytes : 0;
     hipStream_t s = (hipStream_t)stream;
 
-    if (kernel == FP8MI_KERNEL_AUTO) kernel = choose_kernel(p);   // (every id it returns passes its own envelope check below)
+    if (kernel == FP8MI_KERNEL_AUTO) {
+        kernel = choose_kernel(p);   // (every id it returns passes its own envelope check below)
+        // The generic kernel is the device path of last resort (one wave per OUTPUT ELEMENT, byte loads): correct for every problem the reference
+        // accepts (fp8_mps_native.py:55-60 only asks for contiguity), and orders of magnitude slower than the tile kernels.  A large problem that
+        // lands on it - K, lda or ldb not a multiple of 16, or a base pointer that is not 16-byte aligned (a sliced weight view) - says so ONCE per
+        // process on stderr (FP8MI_QUIET=1 silences it); the Python op layer pads such operands into aligned copies instead (fp8_mi355x_native.py).
+        if (kernel == FP8MI_KERNEL_GENERIC && K > 0 && ((double)N * (double)K >= 1048576.0 || (double)M * (double)K >= 1048576.0)) {
+            static std::atomic<bool> told{false};
+            if (!told.exchange(true)) {
+                const char *q = getenv("FP8MI_QUIET");
+                if (!(q && q[0] == '1'))
+                    fprintf(stderr, "[fp8mi] note: M=%lld N=%lld K=%lld (lda=%lld ldb=%lld, A %% 16 = %d, B %% 16 = %d) runs on the GENERIC kernel: the MFMA "
+                                    "kernels need K, lda and ldb to be multiples of 16 and 16-byte aligned operands. Pad K with zero bytes / align the rows "
+                                    "(fp8_mi355x_native.fp8_scaled_mm does so by itself). This note is printed once.\n",
+                            (long long)M, (long long)N, (long long)K, (long long)lda, (long long)ldb, (int)((uintptr_t)A & 15), (int)((uintptr_t)B_nk & 15));
+            }
+        }
+    }
     switch (kernel) {
     case FP8MI_KERNEL_GEMV:
         if (!fp8mi_gemv_supported(p)) return fail(FP8MI_E_UNSUPPORTED, "gemv kernel needs M == 1, K %% 16 == 0, 16-byte aligned rows");

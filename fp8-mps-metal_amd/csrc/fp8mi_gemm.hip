@@ -61,6 +61,12 @@ struct Cfg {
     static constexpr int KS = KS_;      // K-steps (of 128 bytes) per ring stage: KS = 2 halves the barriers per byte
     static constexpr int PFD = ABL_ & 7;  // L2 prefetch distance in ring stages beyond the stage being staged (0 = none): see prefetch_stage
     static constexpr int PFA = (ABL_ >> 3) & 1;  // diagnostic variants: one more wave warms this tile's share of its A panel's lines too
+    // Timing-only FLOOR forms of a tile kernel (wrong results; instantiated ONLY by tools/ceiling_probe.hip, which compiles this file with
+    // FP8MI_FLOOR_PROBE for bench.py's `roofline.floor`): 1 = the K loop's LDS-DMA stream, waits and barriers without fragment reads and MFMAs;
+    // 2 = no K loop at all (launch, arguments, tile map, the C store of the fused epilogue, kernel end); 3 = return behind the argument loads
+    // (the launch itself with this kernel's grid, block and LDS allocation).  What each leaves out is hidden under the others in the real
+    // kernel, so the floors bound the kernel from below; they do not add up to it.
+    static constexpr int FLOOR = (ABL_ >> 4) & 3;
     static constexpr int MODE = MODE_;  // 0: stage DMA issued first, then fragment reads + MFMAs; 1: fragment reads first (see run_tile)
     static constexpr int NSTAGE = NSTAGE_;
     static constexpr int PF = NSTAGE_ - 1;  // K-steps of loads in flight
@@ -293,26 +299,30 @@ FP8MI_DEVICE void run_tile(const MMParams &p, uint8_t *smem, const StagePlan<C> 
             // K-step on the 256x256 tile, in-kernel stamps) and the MFMAs start the moment the issue is through
             i32x8 xf[C::TM], wf[C::TN];
             const uint8_t *st = smem + slot * C::kStageBytes;
-            load_frags<C, SCRUB>(st, st + C::kGroupsA * 1024, wm0, wn0, off1, off2, xf, wf);
+            if constexpr (C::FLOOR == 0) load_frags<C, SCRUB>(st, st + C::kGroupsA * 1024, wm0, wn0, off1, off2, xf, wf);
             __builtin_amdgcn_sched_barrier(0);
             if (t + C::PF < nk) {
                 issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, next_ks(), nk_all, ktail, K);
                 prefetch(t + C::PF + C::PFD);
             }
             STAMP(s3);
-            mfma_all<C>(xf, wf, acc);
+            if constexpr (C::FLOOR == 0) {
+                mfma_all<C>(xf, wf, acc);
 #pragma unroll
-            for (int q = 1; q < C::KS; ++q)
-                compute_step<C, SCRUB>(st + q * C::kStepBytes, wm0, wn0, off1, off2, acc);
+                for (int q = 1; q < C::KS; ++q)
+                    compute_step<C, SCRUB>(st + q * C::kStepBytes, wm0, wn0, off1, off2, acc);
+            }
         } else {
             if (t + C::PF < nk) {
                 issue_any<C>(pl, ra, rb, smem + fill * C::kStageBytes, wave, next_ks(), nk_all, ktail, K);
                 prefetch(t + C::PF + C::PFD);
             }
             STAMP(s3);
+            if constexpr (C::FLOOR == 0) {
 #pragma unroll
-            for (int q = 0; q < C::KS; ++q)
-                compute_step<C, SCRUB>(smem + slot * C::kStageBytes + q * C::kStepBytes, wm0, wn0, off1, off2, acc);
+                for (int q = 0; q < C::KS; ++q)
+                    compute_step<C, SCRUB>(smem + slot * C::kStageBytes + q * C::kStepBytes, wm0, wn0, off1, off2, acc);
+            }
         }
         STAMP(s4);
         c_wait += s1 - s0; c_bar += s2 - s1; c_issue += s3 - s2; c_comp += s4 - s3;
@@ -421,6 +431,10 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThr
     using C = Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>;
     const MMParams p = pin_params(p_in);  // every kernel argument in one scalar-load clause (fp8mi_common.h)
     FP8MI_PIN_S(tiles_m); FP8MI_PIN_S(tiles_n); FP8MI_PIN_S(vec_store); FP8MI_PIN_S(nwg);
+    if constexpr (C::FLOOR == 3) {   // timing-only (tools/ceiling_probe.hip): the launch alone - arguments fetched and used, nothing else
+        if (p.M < 0) *(volatile int *)p.C = tiles_m + tiles_n + vec_store + nwg;   // (never true: keeps the argument loads alive)
+        return;
+    }
     const EpiScalars es = load_epi_scalars(p);  // in flight under the K loop
     __shared__ __attribute__((aligned(16))) uint8_t smem[C::kRingBytes + kFlagBytes];
     if (threadIdx.x == 0) *(volatile int *)(smem + C::kRingBytes) = 0;  // NaN verdict word (ordered by the K loop's barriers)
@@ -511,6 +525,12 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThr
     const int rot = 0;
 
     f32x4 acc[C::TN][C::TM];
+    if constexpr (C::FLOOR == 2) {   // timing-only: no K loop (the accumulators are zero: the epilogue stores a tile of zeros)
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm) acc[tn][tm] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    } else
     run_tile_any<C, false>(p, smem, pl, ra, rb, wave, wm0, wn0, off1, off2, ks0, nk, rot, acc);
 
     // ---- end of the K loop: one barrier frees the ring and carries the NaN verdict (fp8mi_gemm_epi.h) ----
@@ -702,6 +722,14 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     case FP8MI_KERNEL_GEMM_128D: return launch<128, 128, 64, 32, 4, 1, 0, 1, 4>(p, s);
     case FP8MI_KERNEL_GEMM_256W: return fp8mi_launch_gemm256(p, 0, s);                   // (only chosen above when fp8mi_gemm256_supported)
     case FP8MI_KERNEL_GEMM_256x128W: return fp8mi_launch_gemm256(p, 1000, s);
+#ifdef FP8MI_FLOOR_PROBE  // tools/ceiling_probe.hip only (never in libfp8mi.so): timing-only floors of the kernels bench.py's headline workloads run on
+    case 901: return launch<128, 64, 32, 32, 3, 1, 1 | (1 << 4), 2, 4>(p, s);   // FP8MI_KERNEL_GEMM_128x64 (config C3): DMA stream only
+    case 902: return launch<128, 64, 32, 32, 3, 1, 1 | (2 << 4), 2, 4>(p, s);   //   ... launch + C store only
+    case 903: return launch<128, 64, 32, 32, 3, 1, 1 | (3 << 4), 2, 4>(p, s);   //   ... launch only
+    case 911: return launch<128, 128, 64, 32, 4, 1, 0 | (1 << 4), 1, 4>(p, s);  // FP8MI_KERNEL_GEMM_128D (the `wide` class): the same three
+    case 912: return launch<128, 128, 64, 32, 4, 1, 0 | (2 << 4), 1, 4>(p, s);
+    case 913: return launch<128, 128, 64, 32, 4, 1, 0 | (3 << 4), 1, 4>(p, s);
+#endif
 #ifdef FP8MI_DIAG  // schedule variants kept for A/B timing (diagnostic library only; same results): tools/ab_kernels.py
     case 30: return launch<256, 256, 128, 64, 2, 1, 0, 1, 4>(p, s);            // 256x256, fragment reads before the stage DMA
     case 31: return launch<128, 128, 64, 32, 2, 1, 0, 1, 4>(p, s);             // 128x128, same

@@ -186,8 +186,32 @@ def fp8_scaled_mm(A: torch.Tensor, B: torch.Tensor, scale_a: torch.Tensor, scale
         B = B.contiguous()
     lda = max(A.stride(0), K) if M > 1 else max(K, 1)
     ldb = max(B.stride(0), K) if N > 1 else max(K, 1)
+    # The MFMA / vec-mat kernels read 16-byte pieces: K, lda, ldb multiples of 16 and 16-byte aligned bases.  Anything else the reference
+    # accepts (fp8_mps_native.py:55-60 asks for contiguity only: K = 4100, a sliced weight view) would run on the library's generic kernel -
+    # one wave per output element, orders of magnitude slower (M=N=4096, K=4100: profiles/r04_unaligned.txt).  Large such problems are
+    # copied once per call into aligned buffers whose rows are padded with ZERO bytes up to the next multiple of 16: a zero byte is +0.0
+    # in e4m3, so the padded product is the same sum (tests/test_gpu_parity.py::test_unaligned_operands_take_the_padded_mfma_path).
+    if kernel == _l.KERNEL_AUTO and K > 0 and M >= 2 and M * N * K >= PAD_MIN_MACS and not (_aligned16(A, M, K, lda) and _aligned16(B, N, K, ldb)):
+        A, B, K, lda, ldb = _pad_operands(A, B, M, N, K)
     return _scaled_mm_core(A, B, M, N, K, lda, ldb, dev, scale_a, scale_b, bias, scale_result, out_dtype, nan_mode,
                            kernel, split_k, out, transposed_epilogue)
+
+
+PAD_MIN_MACS = 1 << 22   # below this many multiply-adds the generic kernel is as fast as two extra copy launches; a single row (M = 1) never pays for
+                         # a copy of the whole weight matrix (K=4100 N=4096: generic 22.6 us, padded 33.0: profiles/r04_unaligned.txt)
+
+
+def _aligned16(t, rows, K, ld):
+    return K % 16 == 0 and t.data_ptr() % 16 == 0 and (rows <= 1 or ld % 16 == 0)
+
+
+def _pad_operands(A, B, M, N, K):
+    """-> (A', B', K', lda', ldb'): fresh, contiguous (so 16-byte aligned) copies with rows zero-padded to K' = the next multiple of 16."""
+    Kp = (K + 15) // 16 * 16
+    if Kp != K:
+        pad = torch.nn.functional.pad
+        return pad(A, (0, Kp - K)), pad(B, (0, Kp - K)), Kp, Kp, Kp
+    return A.contiguous().clone() if A.data_ptr() % 16 else A.contiguous(), B.contiguous().clone() if B.data_ptr() % 16 else B.contiguous(), K, K, K
 
 
 def _scaled_mm_core(a_keep, b_keep, M, N, K, lda, ldb, dev, scale_a, scale_b, bias, scale_result, out_dtype, nan_mode,

@@ -521,6 +521,46 @@ def test_generic_kernel_unaligned(native, cuda, oracle):
     assert np.all(np.abs(got - exact) <= MM_TOL * bound + 1e-30)
 
 
+@pytest.mark.parametrize("M,K,N", [(300, 4100, 272), (520, 1000, 136), (2, 4100, 4096), (4, 4099, 2048), (64, 2050, 1024)])
+def test_unaligned_operands_take_the_padded_mfma_path(native, cuda, oracle, M, K, N):
+    """K % 16 != 0 (the reference accepts any contiguous shape, fp8_mps_native.py:55-60): above PAD_MIN_MACS multiply-adds the op layer copies both
+    operands into aligned buffers whose rows are zero-padded to the next multiple of 16 and the MFMA / vec-mat kernels run - same sum (a zero byte is
+    +0.0), bit-identical to the call on explicitly padded operands, and within the matrix core's bound of the f64 oracle on the UNPADDED bytes."""
+    assert M * N * K >= native.PAD_MIN_MACS
+    rng = np.random.default_rng(M + K + N)
+    A, B = clean_bytes(rng, (M, K)), clean_bytes(rng, (N, K))
+    A[0, :] = 0xFF if M > 1 else A[0, :]     # NaN bytes (reference: decode to 0) ride along
+    sa, sb = [0.02], rng.uniform(0.01, 0.03, size=N).astype(np.float32)
+    got = native.fp8_scaled_mm(dev(A, cuda), dev(B, cuda), dev(np.asarray(sa, np.float32), cuda), dev(sb, cuda))
+    Kp = (K + 15) // 16 * 16
+    Ap, Bp = np.zeros((M, Kp), np.uint8), np.zeros((N, Kp), np.uint8)
+    Ap[:, :K], Bp[:, :K] = A, B
+    assert L.load().fp8mi_choose_kernel(M, N, Kp, Kp, Kp, N, L.F32, 1, 0) != L.KERNEL_GENERIC
+    want = native.fp8_scaled_mm(dev(Ap, cuda), dev(Bp, cuda), dev(np.asarray(sa, np.float32), cuda), dev(sb, cuda))
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    exact = oracle.scaled_mm(A, B, sa, sb, accumulate="f64")
+    bound = oracle.abs_dot_bound(A, B, sa, sb)
+    assert np.all(np.abs(got.cpu().numpy().astype(np.float64) - exact) <= MFMA_TOL * bound + 1e-30)
+
+
+def test_misaligned_views_take_the_padded_mfma_path(native, cuda, oracle):
+    """A sliced weight view (base pointer off by 8 bytes, row stride not a multiple of 16): copied once per call into aligned rows; the forced
+    generic kernel on the same views is the checker of last resort (exact fp32 sums) and the oracle the judge."""
+    rng = np.random.default_rng(77)
+    big = clean_bytes(rng, (600, 1100))
+    tA, tB = dev(big, cuda)[8:264, 8:1032], dev(big, cuda)[300:556, 24:1048]   # (256, 1024) each: K aligned, bases and strides are not
+    assert tA.data_ptr() % 16 != 0 and tA.stride(0) % 16 != 0 and 256 * 256 * 1024 >= native.PAD_MIN_MACS
+    one = torch.ones(1)
+    got = native.fp8_scaled_mm(tA, tB, one, one)
+    slow = native.fp8_scaled_mm(tA, tB, one, one, kernel=L.KERNEL_GENERIC)
+    torch.cuda.synchronize()
+    exact = oracle.scaled_mm(big[8:264, 8:1032], big[300:556, 24:1048], [1.0], [1.0], accumulate="f64")
+    bound = oracle.abs_dot_bound(big[8:264, 8:1032], big[300:556, 24:1048], [1.0], [1.0])
+    assert np.all(np.abs(got.cpu().numpy() - exact) <= MFMA_TOL * bound + 1e-30)
+    assert np.all(np.abs(slow.cpu().numpy() - exact) <= MM_TOL * bound + 1e-30)
+
+
 def test_tall_problem_grid_math(native, cuda, oracle):
     """M beyond 65535 (grid.y/z split of the generic kernel, many m-tiles of the tile kernels)."""
     rng = np.random.default_rng(12)

@@ -8,6 +8,7 @@ R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun exports it)}; O="$R/gpurun_out/
 export HIP_FORCE_DEV_KERNARG=1   # what bench.py runs with
 # the ceiling probe is built HERE, outside the profiler (bench.py never compiles: hipcc execs clang, an exec hop behind a GPU-initialising preload)
 { [ -f tools/libceiling_probe.so ] && [ ! tools/ceiling_probe.hip -nt tools/libceiling_probe.so ]; } || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -shared tools/ceiling_probe.hip -o tools/libceiling_probe.so
+{ [ -f tools/libfloor_probe.so ] && [ ! tools/floor_probe.hip -nt tools/libfloor_probe.so ] && [ ! fp8-mps-metal_amd/csrc/fp8mi_gemm.hip -nt tools/libfloor_probe.so ]; } || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -shared -fvisibility=hidden -std=c++17 tools/floor_probe.hip -o tools/libfloor_probe.so
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -o kt -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/kt.err" || { echo "kernel-trace run failed"; tail -5 $O/kt.err; exit 1; }
 python tools/summarize_prof.py "$O/kt" > "$O/kernel_trace_summary.txt"
 for w in gemm gemv gemv_sq flux mid wide skinny decode quantize quantize_rne dequant; do
