@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "fp8mi_common.h"
+#include "fp8mi_dispatch.h"
 
 int fp8mi_launch_dequant(const uint8_t *in, void *out, const float *scale, int64_t count, int out_dtype, hipStream_t s);
 int fp8mi_launch_encode(const void *in, int in_dtype, uint8_t *out, const float *prescale, int64_t count, int mode,
@@ -73,108 +74,9 @@ int fp8mi_cu_count()
     return n;
 }
 
-// The kernel the automatic dispatch runs for a problem (host-only arithmetic on shapes, strides, alignment and the CU count;
-// exported as fp8mi_choose_kernel and tested on the CPU).  Rules and the measurements behind them:
-static int choose_kernel(const MMParams &p)
-{
-    if (fp8mi_gemv_supported(p)) return FP8MI_KERNEL_GEMV;
-    if (p.M >= 2 && p.M <= 8 && p.K > 0 && p.K <= 6144 && fp8mi_gemm_supported(p) && (p.N + 63) / 64 >= fp8mi_cu_count() / 2) {   // (M = 2 since the regret sweep: K=1024 N=16384 5.3 against 9.3 us, K=2048 N=13824 7.3 against 8.8)
-        // a few rows against a WIDE, shallow weight matrix: N alone fills the chip with unsplit 32-row tiles, which stream W through the LDS-DMA ring
-        // while the few-rows kernel re-reads x per group of weight rows (round 3, tools/time_shape.py: M=4 K=4096 N=14336 12.1 against 14.6 us,
-        // M=8 11.9 against 14.8; M=4 K=3072 N=12288 8.8 against 12.1; M=8 K=4096 N=8192 9.8 against 13.0; M=2: equal, stays below); up to N = 8192 the
-        // 32x32 tile (twice the workgroups; K=2048 N=8192 M=4: 5.6 against 7.8 us)
-        // (beyond one round of 64-column tiles - N > 64 CUs - 64x128 tiles: K=4096 N=28672 M=8 18.4 against 20.2 us)
-        if ((p.N + 63) / 64 > fp8mi_cu_count()) return FP8MI_KERNEL_GEMM_64x128;
-        return p.N <= 8192 ? FP8MI_KERNEL_GEMM_32x32 : FP8MI_KERNEL_GEMM_32x64;
-    }
-    const double nk_bytes = (double)p.N * (double)p.K;
-    // (2..4 rows: the few-rows kernel keeps N < 5120 - K=N=4096 M=4: 6.1 against 7.4 us, K=14336 N=4096: 12.2 against 13 - but not wider matrices - M=4 K=13824 N=9216: 25.4 against
-    //  20.0 us on 32x64 tiles, K=9216 N=8192 18.8 against 15.8, K=2560 N=5120 6.4 against 5.3 - nor K > 16384, which it does not take: M=4 K=28672 N=4096 20.5 against 24.2)
-    const bool small_rows = p.M >= 5 || (p.M >= 2 && !fp8mi_gemv_mx_supported(p)) || (p.M >= 3 && p.N >= 5120);   // (M = 2 stays: K=8192 N=5120 8.8 against 13.5 us)
-    // (129..256 rows against a small, NARROW matrix - 128x64 tiles on at most a quarter of the CUs: M=160 K=8192 N=1024 8.8 against 14.4 us, M=160 K=2560 N=1536 5.2 against 7.4;
-    //  with a wide shallow one the small tiles only multiply the x traffic: M=256 K=1536 N=7168 15.7 against 7.8)
-    const bool narrow = p.M <= 256 && nk_bytes <= 12.0 * 1048576.0 && ((p.M + 127) / 128) * ((p.N + 63) / 64) * 4 <= fp8mi_cu_count();
-    if (small_rows && (p.M <= 128 || narrow) && p.K >= 1024 && p.ws && p.split != 1 && fp8mi_gemm_supported(p) && nk_bytes >= 1.0 * 1048576.0) {
-        // The small-batch regime on the SMALL tile kernels with the automatic K split (round 3; tools/sweep_decode.py on MI355X, six (K, N)
-        // from 4096^2 to 14336 x 4096, M = 9 .. 128): 32x64 tiles for M <= 32 (K=14336 N=4096: 12.9-13.2 us against 16.5-17.2 on 64x128 x 8
-        // slices; K=12288 N=3072 11.4 against 15.8-16.2; K=N=4096 8.2-8.4 against the skinny kernel's 8.5-10.2), 64x64 tiles for M <= 64
-        // (14.3-14.9 against 17.2-17.4) and on to M = 128 while 128x64 tiles would leave half the CUs idle (K=N=4096 M=96: 9.5 against 13.2;
-        // K=N=8192 M=96: 19.0 against 22.5) - except M > 96 against K > 8192, where 128x64 x split stays 3-6 % ahead.
-        // From M = 5 (the LLM-shape sweep, profiles/r03_llm_shapes.txt: M=8 K=13824 N=5120 14.6 against 26.6 us on the few-rows kernel, K=4096 N=6144 7.7
-        // against 11.8; M <= 4 stays there).  A matrix so wide that 64-column tiles need more than one round (N > 64 CUs) takes 64x128 tiles for M <= 64
-        // (K=5120 N=27648 M=64: 26.9 against 32.8 us).
-        // End of round 3 (tools/sweep_regret.py, profiles/r03_regret.txt): the entry conditions were K >= 2048 and N K >= 12 MiB; on SMALLER weight matrices the
-        // 32x32 tile wins just as clearly (M=8 K=7168 N=1536: 7.0 against 11.8 us on the few-rows kernel; M=128 K=3072 N=2048: 5.9 against 9.5 on 128x64;
-        // M=12 K=1024 N=7168: 4.3 against 6.0 on the skinny kernel; M=48 K=1536 N=8192: 5.2 against 7.4): now K >= 1024 and N K >= 1 MiB.
-        const int64_t cus = fp8mi_cu_count(), t64 = ((p.M + 127) / 128) * ((p.N + 63) / 64);
-        if (p.M <= 64 && (p.N + 63) / 64 > cus) return FP8MI_KERNEL_GEMM_64x128;
-        if (nk_bytes <= 12.0 * 1048576.0 || p.K <= 4096) {
-            // A small matrix or a shallow K (end of round 3, tools/sweep_regret.py): the LARGEST of the three small tiles whose grid fills the chip (75-100 % of the CUs)
-            // - M=64 K=1024 N=12288: 64x64 = 192 tiles 4.9 us, 32x64 = 384 tiles 7.2; M=48 K=3072 N=6144: 32x64 = 192 tiles 8.3, 64x64 = 96 tiles x 2 slices 10.1;
-            // M=128 K=3072 N=2048: 32x32 = 256 tiles 5.9, 64x64 = 64 tiles 7.5 - and when none does, the SMALLEST whose grid can be split (at most half the CUs; against a
-            // shallow K an unsplit grid on 50-75 % of the CUs still beats the split: M=16 K=2048 N=5120, 160 tiles of 32x32 4.9 us, 80 of 32x64 x 2 slices 6.5;
-            // M=160 K=8192 N=1024: 32x32 = 160 tiles 11.1, 32x64 = 80 tiles x 3 slices 8.8)
-            const int64_t t3 = ((p.M + 63) / 64) * ((p.N + 63) / 64), t2 = ((p.M + 31) / 32) * ((p.N + 63) / 64), t1 = ((p.M + 31) / 32) * ((p.N + 31) / 32);
-            auto fills = [&](int64_t t, int quarters) { return t * 4 >= cus * quarters && t <= cus; };   // (one round: M=96 K=4096 N=14336, 448 tiles of 64x64, 19.6 us against 16.0 on 224 of 128x64)
-            auto splits = [&](int64_t t) { return t <= cus / 2 || (p.K <= 4096 && t <= 2 * cus); };
-            // (against a shallow K half a round unsplit still beats more than one round of a smaller tile: M=48 K=4096 N=10240, 160 tiles of 64x64 11.9 us, 320 of 32x64 17.2)
-            for (int quarters = 3; quarters >= (p.K <= 4096 ? 2 : 3); --quarters) {
-                if (p.M > 32 && fills(t3, quarters)) return FP8MI_KERNEL_GEMM_64x64;
-                if (fills(t2, quarters)) return FP8MI_KERNEL_GEMM_32x64;
-                if (fills(t1, quarters) && p.K <= 8192) return FP8MI_KERNEL_GEMM_32x32;   // (against a deeper K the smallest tile's doubled x traffic loses to a split: M=192 K=12288 N=1024 16.3 against 12.3 us)
-            }
-            // (deep K: the larger tile first while its slices stay at least 2 KiB deep - M=192 K=12288 N=1024: 64x64 x 5 slices 12.3 us, 32x64 x 2 15.1; but M=64 K=9216 N=1024:
-            //  16 tiles of 64x64 x 16 slices 10.0, 64 of 32x32 x 4 7.6)
-            auto deep_enough = [&](int64_t t) { return t * p.K >= cus * 2048; };
-            if (p.K > 8192 && p.M > 32 && splits(t3) && deep_enough(t3)) return FP8MI_KERNEL_GEMM_64x64;
-            if (p.K > 8192 && splits(t2) && deep_enough(t2)) return FP8MI_KERNEL_GEMM_32x64;
-            if (splits(t1)) return FP8MI_KERNEL_GEMM_32x32;
-            if (splits(t2)) return FP8MI_KERNEL_GEMM_32x64;
-            if (p.M > 128) return FP8MI_KERNEL_GEMM_64x64;
-        }
-        // ... and 32x32 tiles where K and N stay within 8192: twice the tiles = half the K slices (none at N = 8192), the partial exchange being what the
-        // regime pays for (K=N=8192 M=32: 14.7 against 18.0 us; K=N=4096: 7.2 against 8.1); against a deeper K their doubled x traffic loses (K=12288 N=3072: 12.3 against 11.6)
-        if (p.M <= 32) return ((p.N <= 8192 && p.K <= 8192) || p.N <= 2048) ? FP8MI_KERNEL_GEMM_32x32 : FP8MI_KERNEL_GEMM_32x64;   // (a narrow N at any K: M=16 K=14336 N=1536 9.1 against 10.5 us)
-        if (p.M <= 64 && (double)p.N * (double)p.K <= 16.0 * 1048576.0 && ((p.M + 31) / 32) * ((p.N + 31) / 32) <= 2 * cus) return FP8MI_KERNEL_GEMM_32x32;   // (K=N=4096, M=48-64: 7.6 against 9.4 us on 64x64; at most two rounds: M=64 K=1024 N=16384, 1024 tiles, 7.9 against 5.5)
-        // (33..64 rows against N = 8192-ish: two rows of 32x64 tiles are one whole round with NO K split, i.e. no partial exchange, where 64x64 tiles need
-        //  2 slices - K=N=8192 M=33 / 48 / 64: 15.7 / 17.4 / 18.0 against 19.3 / 19.2 / 19.1 us, K=4096 9.4-10.5 against 10.4-10.8; at N = 7936, 248 tiles, 64x64 x 2 is 6 % ahead again and stays)
-        if (p.M <= 64 && p.K <= 8192 && 2 * ((p.N + 63) / 64) <= cus && 2 * ((p.N + 63) / 64) > cus - 4) return FP8MI_KERNEL_GEMM_32x64;
-        if (p.M <= 64) {
-            // (64x64 tiles unsplit on 50-75 % of the CUs against a deep K: 64x128 tiles with the K split instead - M=64 K=14336 N=9216: 27.8 against 35.7 us)
-            const int64_t t = (p.N + 63) / 64;
-            if (p.K >= 8192 && t > cus / 2 && t * 4 <= cus * 3) return FP8MI_KERNEL_GEMM_64x128;
-            return FP8MI_KERNEL_GEMM_64x64;
-        }
-        // (65..128 rows: 64x64 tiles either fill at most half the chip - then the K split does - or most of it; in between they run unsplit on ~60 % of the CUs:
-        //  M=96 K=28672 N=5120, 160 tiles: 57.5 us against 40.2 on 128x64 x 3 slices)
-        const int64_t t6464 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
-        const bool underfilled = p.K >= 8192 && t6464 > cus / 2 && t6464 * 4 < cus * 3;
-        if (t64 <= cus / 2 && !(p.M > 96 && p.K > 8192 && p.N >= 4096) && !underfilled) return FP8MI_KERNEL_GEMM_64x64;   // (a narrow N keeps 64x64 at M = 128 too: K=13824 N=1536 12.9 against 15.3 us)
-    }
-    if (fp8mi_gemv_mx_supported(p)) {
-        // 2..8 rows of x on the vec-mat's weight-streaming structure (tools/check_gemv_mx.py time, MI355X): ahead of
-        // the skinny and the split-K tile kernel for M <= 4 everywhere measured (K = N = 4096: 5.6 / 6.3 vs 7.8 us;
-        // K = 14336, N = 4096: 12.2 vs 16-17 us) and for 5 <= M <= 8 once K > 4096 on matrices the tile kernel
-        // cannot fill the chip with (K = 14336, N = 4096: 14.3 vs 17.4 us; K = N = 8192: 15.1 vs 17.9 us)
-        const int64_t t64 = (p.N + 63) / 64, cus = fp8mi_cu_count();
-        if (p.M <= 4 || (p.K > 4096 && t64 < (3 * cus) / 4)) return FP8MI_KERNEL_GEMV_MX;
-    }
-    if (p.M >= 2 && p.M <= 48 && fp8mi_skinny_supported(p)) {
-        // measured (tools/sweep_small_m.py): on small weight matrices the weight-streaming skinny kernel wins up
-        // to M = 48 (K = N = 4096: 8.5-11.4 vs 11.4-12.6 us); on large ones (N*K >= 24 MiB) the split-K tile
-        // kernel wins from M = 2 (K = 4096, N = 14336: 13.7 vs 25.4 us; M = 32, K = 14336, N = 4096: 17.7 vs
-        // 28.4 us) - it needs the workspace
-        const bool big = (double)p.N * (double)p.K >= 24.0 * 1048576.0;
-        // ... and when N alone yields >= 192 tiles of 128x64 the tile kernel needs no split to fill the chip
-        // (K = 4096, N = 14336: 14-15 us for every M <= 64, skinny 20-36 us: x is re-read by every 16-row workgroup)
-        // (from 128 tiles on while K <= 4096: K = 4096, N = 8192: 14-15 vs 16-19 us; at K = 8192 the 128 busy CUs lose)
-        const int64_t t64 = (p.N + 63) / 64, cus = fp8mi_cu_count();
-        const bool wide = t64 >= (3 * cus) / 4 || (t64 >= cus / 2 && p.K <= 4096);
-        if (!(fp8mi_gemm_supported(p) && ((p.ws && p.split != 1 && big) || wide))) return FP8MI_KERNEL_SKINNY;
-    }
-    if (p.K > 0 && fp8mi_gemm_supported(p)) return fp8mi_choose_gemm_variant(p);
-    return FP8MI_KERNEL_GENERIC;
-}
+// The kernel the automatic dispatch runs for a problem: the cheapest by the cost model of fp8mi_dispatch.h (host-only arithmetic on shapes,
+// strides, alignment and the CU count; exported as fp8mi_choose_kernel, tested on the CPU against measured times).
+static int choose_kernel(const MMParams &p) { return fp8mi_dispatch::choose(p, (double)fp8mi_cu_count()); }
 
 extern "C" {
 
@@ -371,10 +273,8 @@ int fp8mi_scaled_mm_ws(const uint8_t *A, const uint8_t *B_nk, void *C, const flo
     }
 }
 
-int fp8mi_choose_kernel(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int out_dtype, int has_workspace,
-                        int split_k)
+static MMParams shape_only_params(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int out_dtype, int has_workspace, int split_k)
 {
-    if (M < 0 || N < 0 || K < 0 || !dtype_ok(out_dtype) || split_k < 0) return FP8MI_E_ENUM;
     MMParams p = {};
     p.A = (const uint8_t *)(uintptr_t)0x10000; p.B = (const uint8_t *)(uintptr_t)0x20000; p.C = (void *)(uintptr_t)0x30000;   // aligned, never dereferenced
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -382,8 +282,23 @@ int fp8mi_choose_kernel(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ld
     p.nan_zero = 1;
     p.split = has_workspace ? split_k : 1;
     p.ws = has_workspace ? (uint8_t *)(uintptr_t)0x40000 : nullptr;
-    p.ws_bytes = has_workspace ? (int64_t)1 << 30 : 0;
-    return choose_kernel(p);
+    p.ws_bytes = has_workspace ? fp8mi_scaled_mm_workspace_bytes() : 0;
+    return p;
+}
+
+int fp8mi_choose_kernel(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int out_dtype, int has_workspace,
+                        int split_k)
+{
+    if (M < 0 || N < 0 || K < 0 || !dtype_ok(out_dtype) || split_k < 0) return FP8MI_E_ENUM;
+    return choose_kernel(shape_only_params(M, N, K, lda, ldb, ldc, out_dtype, has_workspace, split_k));
+}
+
+double fp8mi_predict_kernel_us(int kernel, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int out_dtype, int has_workspace,
+                               int split_k, int compute_units)
+{
+    if (M < 0 || N < 0 || K < 0 || !dtype_ok(out_dtype) || split_k < 0) return -1.0;
+    const MMParams p = shape_only_params(M, N, K, lda, ldb, ldc, out_dtype, has_workspace, split_k);
+    return fp8mi_dispatch::predict_us(p, kernel, compute_units > 0 ? (double)compute_units : (double)fp8mi_cu_count());
 }
 
 int fp8mi_scaled_mm(const uint8_t *A, const uint8_t *B_nk, void *C, const float *scale_a, const float *scale_b,

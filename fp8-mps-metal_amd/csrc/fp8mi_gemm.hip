@@ -53,6 +53,7 @@
 // never pay for it.
 
 #include "fp8mi_gemm_epi.h"
+#include "fp8mi_dispatch.h"
 
 namespace {
 
@@ -611,90 +612,17 @@ bool fp8mi_gemm_supported(const MMParams &p)
            (((uintptr_t)p.A) & 15u) == 0 && (((uintptr_t)p.B) & 15u) == 0 && p.lda < (1 << 22) && p.ldb < (1 << 22);
 }
 
-// The tile kernel the automatic dispatch uses for a shape the tile kernels support (host-only: fp8mi_choose_kernel, tested on the CPU)
+// The tile kernel the automatic dispatch uses for a shape the tile kernels support: the cheapest tile kernel by the cost model (fp8mi_dispatch.h)
 int fp8mi_choose_gemm_variant(const MMParams &p)
 {
-    int variant = FP8MI_KERNEL_GEMM_128x64;
-    {
-        // Pick the tile by a small cost model fitted to per-dispatch timings on MI355X (tools/sweep_dispatch.py,
-        // DESIGN.md 6): time = rounds x (fixed + per-K-step) in us, where a round is one workgroup per CU
-        // (two for the 128x128 tile) and a partly filled last round costs a + b x its fill (fitted per tile).
-        //   256x256: 8 + 1.6 nk      128x128: 5.5 + 0.87 nk      128x64: 5 + 0.37 nk        (nk = K / 128)
-        // e.g. FLUX 4096x3072x12288: 139 / 158 / 332 -> 256x256; 6144^3: 229 / 227 -> 128x128 (2.25 rounds of
-        // 256x256 tiles waste most of the third); C3 512x4096x4096: one round of 128x64 tiles, 16.8.
-        // The CU count is the device's (a CPX partition has 32): only the slots per round depend on it.
-        const double cus = (double)fp8mi_cu_count();
-        const double nk = (double)((p.K + 127) / 128);
-        auto rounds = [](double tiles, double slots, double a, double b) {  // a partly filled round costs a + b x fill
-            const double r = tiles / slots, whole = (double)(int64_t)r, part = r - whole;
-            return whole + (part > 0 ? a + b * part : 0.0);
-        };
-        const double t256 = (double)(((p.M + 255) / 256) * ((p.N + 255) / 256));
-        const double t128 = (double)(((p.M + 127) / 128) * ((p.N + 127) / 128));
-        const double t64 = (double)(((p.M + 127) / 128) * ((p.N + 63) / 64));
-        // shapes of whole K-steps run on the hand-scheduled one-wave-per-SIMD kernel (fp8mi_gemm256.hip; any M, N): 8.5 + 1.35 nk per
-        // round (FLUX: 40.8 us per tile at nk = 24, in-kernel stamps) against 8 + 1.6 nk for the ring kernel
-        const bool w256 = fp8mi_gemm256_supported(p);
-        const double us256 = rounds(t256, cus, 0.75, 0.25) * (w256 ? 8.5 + 1.35 * nk : 8.0 + 1.6 * nk);  // (a quarter-filled round of 256x256
-        const double us128 = rounds(t128, 2 * cus, 0.55, 0.45) * (5.5 + 1.0 * nk);   //  tiles still costs 0.8 of a full one; 128x128: 0.95-1.07 us per K-step and round in round 3's
-                                                                                    //  sweep - profiles/r03_large_m.txt - where round 1 fitted 0.87: at 0.87 AUTO took it for 2048x12288x3072 at 117 us, 256x128W 75)
-        const double us64 = rounds(t64, cus, 0.6, 0.4) * (5.0 + 0.37 * nk);
-        // ... and its 256x128 form at max(1.5 + 0.89 nk, 4.5 + 0.75 nk) per round (deep K: the DMA stream; shallow K: the per-tile
-        // fixed cost), a partly filled round costing nearly a full one (fitted: 2048x4096x4096 29.8 us, 1024x8192x8192 58.5,
-        // 4096x3072x1536 23.3, 3072^3 45.6, FLUX 136.8, 16384x1024x8192 168.6; profiles/r02_large_shapes.txt)
-        const double t256n = (double)(((p.M + 255) / 256) * ((p.N + 127) / 128));
-        const double per256n = 1.5 + 0.89 * nk > 4.5 + 0.75 * nk ? 1.5 + 0.89 * nk : 4.5 + 0.75 * nk;
-        // (one row of 256x128 tiles on at most half of the CUs: nobody shares a B panel, every CU streams its own from HBM at what ONE CU keeps in
-        //  flight - M = 192 K = 4096 N = 14336: 35.3 us against 28.7 on 128x64 tiles, M = 256 K = 3072 N = 12288: 28.7 against 25.7)
-        const bool lone_row = p.M <= 256 && t256n <= cus / 2;
-        const double us256n = (w256 && !lone_row) ? rounds(t256n, cus, 0.85, 0.15) * per256n : 1e30;
-        if (t64 <= cus / 2) {
-            // few tiles: one per CU at most, split-K (launch<>) fills the rest of the chip when a workspace came along;
-            // with few rows of A the tile is better spent on N
-            variant = (p.M <= 64 && p.ws && p.split != 1) ? FP8MI_KERNEL_GEMM_64x128 : FP8MI_KERNEL_GEMM_128x64;
-        } else if (us256n < us256 && us256n < us128 && us256n < us64) variant = FP8MI_KERNEL_GEMM_256x128W;
-        else if (us256 <= us128 && us256 <= us64) variant = w256 ? FP8MI_KERNEL_GEMM_256W : FP8MI_KERNEL_GEMM_256;
-        else if (us128 <= us64) variant = FP8MI_KERNEL_GEMM_128;
-        else variant = FP8MI_KERNEL_GEMM_128x64;
-        // more than half a round and at most one round of 128x128 tiles: the deep-ring form of that tile, one workgroup per CU (see fp8mi_launch_gemm)
-        if (t128 > cus / 2 && t128 <= cus) variant = FP8MI_KERNEL_GEMM_128D;   // (from K = 256 on it is the best or tied; a second round is not: M=1088 K=N=4096 41.5 against 29.8 us)
-        // Round 3, M = 129 .. 512 (tools/sweep_decode.py with MS=160..512, profiles/r03_mid_m.txt): the fitted model is optimistic about a 128x128 grid
-        // that leaves the CUs one workgroup each (its two co-resident workgroups are what hides its prologue / epilogue) - up to two rounds of 128x64
-        // tiles are faster (M=512 K=N=8192: 51.7 against 59.5 us; M=256 K=4096 N=14336: 29.6 against 31.8) ...
-        if (variant == FP8MI_KERNEL_GEMM_128 && p.M <= 512 && t64 <= 2 * cus) variant = FP8MI_KERNEL_GEMM_128x64;
-        // ... and a shallow K on at most one round of 64x64 tiles beats half a round of 128x64 (M=256 K=N=4096: 11.6 against 14.3 us)
-        const double t6464 = (double)(((p.M + 63) / 64) * ((p.N + 63) / 64));
-        if (variant == FP8MI_KERNEL_GEMM_128x64 && p.M > 128 && p.K <= 4096 && t6464 <= cus && t64 <= cus / 2) variant = FP8MI_KERNEL_GEMM_64x64;
-        // The split-K cliff: 128x64 tiles on 50-60 % of the CUs are too many to split and too few to fill the chip (M=288 K=12288 N=3072, 144 tiles: 34.9 us; M=256,
-        // 96 tiles x 2 slices: 25.3).  One round of 64x64 tiles instead (26.9; K=4096 N=3072 M=288: 10.7 against 14.1), or against a deep K the deep-ring 128x128 tile
-        // (M=384 K=12288 N=3072: 32.0 against 39.5) - profiles/r03_regret.txt
-        if (variant == FP8MI_KERNEL_GEMM_128x64 && p.M > 128 && t64 > cus / 2 && t64 * 5 <= cus * 3) {
-            if (t6464 <= cus) variant = FP8MI_KERNEL_GEMM_64x64;
-            else if (p.K >= 8192) variant = FP8MI_KERNEL_GEMM_128D;
-        }
-        // ... and against a deep K the deep-ring 128x128 tile beats 128x64 tiles that are too many to split even on a quarter of the CUs (M=128 K=N=10240: 29.8 against
-        // 38.8 us; M=192 K=28672 N=6144: 69.1 against 84.2; M=768 K=28672 N=2560: 76.9 against 86.6); at K <= 8192 the 128x64 tile keeps its lead (C3)
-        if (variant == FP8MI_KERNEL_GEMM_128x64 && t64 > cus / 2 && p.K >= 10240 && t128 * 4 >= cus && t128 <= cus) variant = FP8MI_KERNEL_GEMM_128D;
-        // ... and from K = 16384 on even against 128x64 tiles WITH the K split, down to 3/16 of the CUs (the loop is bound by the bytes the whole chip pulls through the L2,
-        // which the larger tile halves per flop: M=320 K=28672 N=2048, 48 tiles, 36.3 against 44.8 us; M=768 K=28672 N=1024 38.1 against 45.0; M=128 K=28672 N=8192 56.0 against 67.3;
-        // not 32 tiles: M=256 K=28672 N=2048 31.7 against 28.7) - profiles/r03_regret.txt
-        if (variant == FP8MI_KERNEL_GEMM_128x64 && t64 <= cus / 2 && p.K >= 16384 && t128 * 16 >= cus * 3) variant = FP8MI_KERNEL_GEMM_128D;
-        // ... unless the last 128-row tile is at most half full and 64x128 tiles fit one round too (M=192 K=N=9216: 25.0 against 39.3 us; M=320 K=3072 N=6144: 14.9 against 17.5;
-        // M=160 K=16384 N=5120: 26.7 against 32.4)
-        // - when that grid is splittable or fills the chip: M=192 K=28672 N=6144, 144 tiles of 64x128 unsplit, 103 us against 69.6)
-        const bool can_split = p.ws != nullptr && p.split != 1;   // (a sharded linear's calls and callers without a workspace run unsplit: a grid on half the CUs stays there)
-        auto fits = [&](double t) { return (can_split && t <= cus / 2) || (t * 5 >= cus * 4 && t <= cus); };
-        const bool half_tile = ((p.M + 63) / 64) % 2 == 1 && p.M <= 320;   // the last 128-row tile is at most half full, of at most three (seven 64-row tiles against four: M=448 K=28672 N=2048 54.0 against 40.8 us)
-        if (variant == FP8MI_KERNEL_GEMM_128D && half_tile && fits((double)(((p.M + 63) / 64) * ((p.N + 127) / 128)))) variant = FP8MI_KERNEL_GEMM_64x128;
-        // ... and 128x64 tiles likewise give way to 64x64 (M=160 K=9216 N=1536: 11.0 against 14.2 us; M=160 K=2560 N=5120: 7.9 against 10.1; not N = 4096 against a deep K,
-        // 192 tiles unsplit: M=192 K=14336 32.9 against 27.5)
-        // (three 64-row tiles against two of 128 - M=448 K=28672 N=2048, seven against four: 61.0 against 44.5 - and, where both grids split, only while the 64x64 grid's
-        //  workgroups x slices fill the chip as well as the other's: M=192 K=28672 N=2048, 96 x 2 against 64 x 4, 35.5 against 27.4; M=160 K=16384 N=1024, 48 x 5 against 32 x 8, 12.3 against 15.7)
-        auto filled = [&](double t) { const double sl = (double)(int64_t)(cus / t); return t * (sl > 16 ? 16 : sl); };
-        if (variant == FP8MI_KERNEL_GEMM_128x64 && p.M > 128 && p.M <= 192 &&
-            (t6464 > cus / 2 ? fits(t6464) : (can_split && t64 <= cus / 2 && filled(t6464) * 10 >= filled(t64) * 9))) variant = FP8MI_KERNEL_GEMM_64x64;
+    const double cus = (double)fp8mi_cu_count();
+    int best = FP8MI_KERNEL_GEMM_128x64;
+    double best_us = 1e300;
+    for (const fp8mi_dispatch::TileCost &t : fp8mi_dispatch::kTileCosts) {
+        const double us = fp8mi_dispatch::predict_us(p, t.id, cus);
+        if (us >= 0.0 && us < best_us) { best_us = us; best = t.id; }
     }
-    return variant;
+    return best;
 }
 
 int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)

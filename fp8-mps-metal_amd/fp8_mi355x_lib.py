@@ -71,6 +71,7 @@ SIGNATURES = {
     "fp8mi_scaled_mm_workspace_bytes": (_i64, []),
     "fp8mi_workspace_reset": (_int, [_vp, _i64, _vp]),
     "fp8mi_choose_kernel": (_int, [_i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _int]),
+    "fp8mi_predict_kernel_us": (ctypes.c_double, [_int, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _int]),
     "fp8mi_dequant": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
     "fp8mi_dequant_f16": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),   # SURVEY 8(b)'s name, same entry point
     "fp8mi_encode": (_int, [_vp, _int, _vp, _vp, _i64, _int, _vp]),

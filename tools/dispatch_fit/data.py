@@ -1,0 +1,26 @@
+"""Measured per-kernel times the dispatch's cost model is fitted on: either the raw output of tools/sweep_regret.py (gpurun_out/, scratch) or the
+committed fixture made from it (tests/golden/dispatch_times_r03.json: median over the repeats of a shape)."""
+import glob, json, os, re, statistics
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+FIXTURE = os.path.join(ROOT, "tests", "golden", "dispatch_times_r03.json")
+LINE = re.compile(r"^M=\s*(\d+) K=\s*(\d+) N=\s*(\d+): auto\((\w+)\)\s+([\d.]+)\s+(.*?)\s+\| auto/best")
+
+
+def load_raw(pattern):
+    """{(M, K, N, out): {kernel: median us}} from sweep_regret.py output files ('f32' in the file name = fp32 output)"""
+    data = defaultdict(lambda: defaultdict(list))
+    for p in sorted(glob.glob(pattern)):
+        out = "f32" if "f32" in os.path.basename(p) else "bf16"
+        for ln in open(p, errors="replace"):
+            m = LINE.match(ln)
+            if m:
+                toks = m.group(6).split()
+                for name, t in zip(toks[0::2], toks[1::2]):
+                    data[(int(m.group(1)), int(m.group(2)), int(m.group(3)), out)][name].append(float(t))
+    return {k: {n: statistics.median(v) for n, v in d.items()} for k, d in data.items()}
+
+
+def load_fixture(path=FIXTURE):
+    return {(M, K, N, out): times for M, K, N, out, times in json.load(open(path))["shapes"]}

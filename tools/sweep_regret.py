@@ -9,6 +9,7 @@ import numpy as np, torch, fp8_mi355x_lib as L
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 OUT_F32 = os.environ.get("OUT", "bf16") == "f32"
+NOWS = os.environ.get("NOWS", "0") == "1"   # callers without a split-K workspace (a sharded linear's calls, a first call inside a graph capture): every kernel runs unsplit
 rng = np.random.default_rng(seed)
 dev = torch.device("cuda:0"); lib = L.load()
 ws = torch.zeros(int(lib.fp8mi_scaled_mm_workspace_bytes()), dtype=torch.uint8, device=dev)
@@ -46,11 +47,11 @@ while done < count:
     A = torch.randint(0, 120, (M, K), dtype=torch.uint8, device=dev, generator=g)
     C = torch.empty(M, N, dtype=torch.float32 if OUT_F32 else torch.bfloat16, device=dev)
     res = {}
-    picked = lib.fp8mi_choose_kernel(M, N, K, K, K, N, 0 if OUT_F32 else 2, 1, 0)
+    picked = lib.fp8mi_choose_kernel(M, N, K, K, K, N, 0 if OUT_F32 else 2, 0 if NOWS else 1, 0)
     for kid in [0] + candidates(M, K, N) + [0]:
         def run(i):
             return lib.fp8mi_scaled_mm_ws(A.data_ptr(), Bs[i % nb].data_ptr(), C.data_ptr(), s1.data_ptr(), s1.data_ptr(), None, None,
-                                          M, N, K, K, K, N, 0, 0, 0 if OUT_F32 else 2, 0, 0, kid, 0, ws.data_ptr(), ws.numel(), st)
+                                          M, N, K, K, K, N, 0, 0, 0 if OUT_F32 else 2, 0, 0, kid, 1 if NOWS else 0, None if NOWS else ws.data_ptr(), 0 if NOWS else ws.numel(), st)
         if run(0) != 0: continue
         for i in range(nb + 2): run(i)
         torch.cuda.synchronize()
