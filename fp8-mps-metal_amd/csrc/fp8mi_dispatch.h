@@ -31,6 +31,7 @@ struct TileCost {
 #include "fp8mi_dispatch_constants.inc"
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+constexpr double kDispatchFloorUs = 4.0;
 
 // K slices the launcher will use (resolve_split in fp8mi_gemm_epi.h, restated on plain numbers; tested against it on the GPU through parity)
 inline int64_t slices(const MMParams &p, const TileCost &t, int64_t tiles, int64_t cus)
@@ -143,7 +144,11 @@ inline int choose(const MMParams &p, double cus)
     int best = FP8MI_KERNEL_GENERIC;   // K = 0, unaligned operands, or nothing above takes the shape
     double best_us = 1e300;
     for (int k : kCandidates) {
-        const double us = predict_us(p, k, cus);
+        double us = predict_us(p, k, cus);
+        // no dispatch of any kernel takes less than ~4 us on this runtime (roofline.floor.empty_launch_us): below that the fitted forms only
+        // extrapolate (they were fitted on K, N >= 1024), so tiny problems tie there and the FIRST candidate - the smallest kernel that takes
+        // the shape - runs
+        if (us >= 0.0 && us < kDispatchFloorUs) us = kDispatchFloorUs;
         if (us >= 0.0 && us < best_us) { best_us = us; best = k; }
     }
     return best;

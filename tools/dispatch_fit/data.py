@@ -22,5 +22,22 @@ def load_raw(pattern):
     return {k: {n: statistics.median(v) for n, v in d.items()} for k, d in data.items()}
 
 
+FIXTURE_R04 = FIXTURE.replace("r03", "r04")
+FIXTURE_NOWS = FIXTURE.replace("r03", "r04_nows")
+
+
 def load_fixture(path=FIXTURE):
     return {(M, K, N, out): times for M, K, N, out, times in json.load(open(path))["shapes"]}
+
+
+def load_all():
+    """round 3's sweeps + round 4's (a shape measured in both: the mean of the two medians)"""
+    a, b = load_fixture(FIXTURE), load_fixture(FIXTURE_R04)
+    out = {k: dict(v) for k, v in a.items()}
+    for k, v in b.items():
+        if k in out:
+            for n, t in v.items():
+                out[k][n] = 0.5 * (out[k][n] + t) if n in out[k] else t
+        else:
+            out[k] = dict(v)
+    return out
