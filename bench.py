@@ -15,6 +15,7 @@ graph, so the number is not bounded by Python launch overhead.
 Workloads (BASELINE.json configs):
   gemm     M=512, K=N=4096, fp32 out   (configs[2]; the N=1 default, TFLOP/s)
   gemv     M=1, K=14336, N=4096        (configs[1]; GB/s of algorithmic bytes)
+  gemv_c1  M=1, K=N=4096               (configs[0] - the reference's CPU-runnable case - on the GPU: one dispatch floor + 16.8 MB)
   flux     M=4096, K=3072, N=12288, bf16 out (configs[3]); with --gpus N > 1 the
            N dimension is column-sharded over the ranks and the output is
            all-gathered over RCCL/xGMI ("strong" scaling: fixed total work)
@@ -107,11 +108,11 @@ MAX_STREAMS = 4
 
 # name -> (M, K, N); "decode" = a small batch against the C2 weight shape (split-K fills the chip)
 # "gemv_sq" = the reference's one published big GEMV shape (test_fp8_metal.py:233-235, README.md:77-82: 2.38 ms on M4 Pro)
-MM_WORKLOADS = {"gemm": (512, 4096, 4096), "gemv": (1, 14336, 4096), "flux": (4096, 3072, 12288),
+MM_WORKLOADS = {"gemm": (512, 4096, 4096), "gemv": (1, 14336, 4096), "gemv_c1": (1, 4096, 4096), "flux": (4096, 3072, 12288),   # gemv_c1 = BASELINE config C1 on the GPU
                 "skinny": (4, 4096, 4096), "decode": (64, 14336, 4096), "gemv_sq": (1, 14336, 14336),
                 "mid": (2048, 4096, 4096),    # "mid" = one round of 256x128 tiles (the mid-size class between C3 and FLUX)
                 "wide": (1024, 4096, 4096)}   # "wide" = twice C3's rows, fp32 out: one 128x128 tile per CU (FP8MI_KERNEL_GEMM_128D)
-WEIGHT_STREAMING = ("gemv", "skinny", "decode", "gemv_sq")   # quoted in GB/s of algorithmic bytes
+WEIGHT_STREAMING = ("gemv", "gemv_c1", "skinny", "decode", "gemv_sq")   # quoted in GB/s of algorithmic bytes
 TARGET_STEP_S = 0.016   # a step lasts >= 16 ms: the driver's 20 steps time >= 0.3 s of sustained work per workload
 
 
@@ -728,6 +729,8 @@ def dtype_of(name):
     """What the workload's kernel computes in (not a precision claim)."""
     if name in ("quantize", "quantize_rne", "dequant"):
         return "u8"
+    if name == "gemv_c1":
+        return "fp8_e4m3fn (M = 1, K <= 4096: decoded products summed in IEEE fp32 FMA, as fp8_matmul.metal:177-199)"
     if name in ("gemv", "gemv_sq"):
         # since round 2 the vec-mat hands K > 4096 to the matrix core too (MFMA-diagonal form); FP8MI_KERNEL_GEMV_FP32 keeps IEEE fp32
         return "fp8_e4m3fn (M = 1, K > 4096: products summed by the fp8 matrix core into fp32, not IEEE fp32 FMA as fp8_matmul.metal:177-199)"
@@ -939,7 +942,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="auto", choices=["auto", "gemm", "gemv", "gemv_sq", "flux", "mid", "wide", "skinny", "decode", "linear",
+    ap.add_argument("--workload", default="auto", choices=["auto", "gemm", "gemv", "gemv_c1", "gemv_sq", "flux", "mid", "wide", "skinny", "decode", "linear",
                                                            "quantize", "quantize_rne", "dequant", "callsite"])
     ap.add_argument("--kernel", type=int, default=L.KERNEL_AUTO, help="force an FP8MI_KERNEL_* id")
     ap.add_argument("--nbuf", type=int, default=None, help="override the number of rotating weight buffers "
@@ -1067,7 +1070,7 @@ def main():
 
     if world == 1 and args.workload == "auto" and not args.no_secondary and not args.force_sharded:
         sec = {}
-        for name in ("gemv", "gemv_sq", "flux", "mid", "wide", "skinny", "decode", "linear", "quantize", "quantize_rne", "dequant"):
+        for name in ("gemv", "gemv_c1", "gemv_sq", "flux", "mid", "wide", "skinny", "decode", "linear", "quantize", "quantize_rne", "dequant"):
             try:
                 r = measure(name, dev, max(3, args.steps // 2), max(1, args.warmup // 2), 1, 0, L.KERNEL_AUTO,
                             with_cpu=(name == "gemv" and not args.no_cpu_baseline), info=info, ceilings=ceilings)

@@ -11,7 +11,7 @@ export HIP_FORCE_DEV_KERNARG=1   # what bench.py runs with
 { [ -f tools/libfloor_probe.so ] && [ ! tools/floor_probe.hip -nt tools/libfloor_probe.so ] && [ ! fp8-mps-metal_amd/csrc/fp8mi_gemm.hip -nt tools/libfloor_probe.so ]; } || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -shared -fvisibility=hidden -std=c++17 tools/floor_probe.hip -o tools/libfloor_probe.so
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -o kt -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/kt.err" || { echo "kernel-trace run failed"; tail -5 $O/kt.err; exit 1; }
 python tools/summarize_prof.py "$O/kt" > "$O/kernel_trace_summary.txt"
-for w in gemm gemv gemv_sq flux mid wide skinny decode quantize quantize_rne dequant; do
+for w in gemm gemv gemv_c1 gemv_sq flux mid wide skinny decode quantize quantize_rne dequant; do
   n=6; [ $w = quantize ] && n=3; [ $w = quantize_rne ] && n=3; [ $w = dequant ] && n=3
   timeout -k 10 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/fetch_$w" -o p -- python tools/run_workload.py $w $n > /dev/null 2>&1 || { echo "FETCH pass failed for $w"; exit 1; }
   timeout -k 10 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write_$w" -o p -- python tools/run_workload.py $w $n > /dev/null 2>&1 || { echo "WRITE pass failed for $w"; exit 1; }
@@ -20,14 +20,14 @@ python - <<PY
 import csv, glob, json, os, collections
 O = "$O"
 out = {}; lines = []
-for w in ("gemm", "gemv", "gemv_sq", "flux", "mid", "wide", "skinny", "decode", "quantize", "quantize_rne", "dequant"):
+for w in ("gemm", "gemv", "gemv_c1", "gemv_sq", "flux", "mid", "wide", "skinny", "decode", "quantize", "quantize_rne", "dequant"):
     vals = {}
     for kind in ("fetch", "write"):
         f = glob.glob(os.path.join(O, f"{kind}_{w}", "**", "*counter_collection.csv"), recursive=True)[0]
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             # the workload's own kernel only (the synthetic-data generator also runs amax / encode kernels)
-            want = {"gemm": ("gemm_kernel",), "flux": ("gemm256_kernel", "gemm_kernel"), "mid": ("gemm256_kernel", "gemm_kernel"), "wide": ("gemm_kernel",), "decode": ("gemm_kernel",), "gemv": ("gemv_mx_kernel", "gemv_kernel"),
+            want = {"gemm": ("gemm_kernel",), "flux": ("gemm256_kernel", "gemm_kernel"), "mid": ("gemm256_kernel", "gemm_kernel"), "wide": ("gemm_kernel",), "decode": ("gemm_kernel",), "gemv": ("gemv_mx_kernel", "gemv_kernel"), "gemv_c1": ("gemv_kernel", "gemv_mx_kernel"),
                     "gemv_sq": ("gemv_kernel",), "skinny": ("gemv_mx_kernel", "skinny_kernel"), "quantize": ("encode_kernel<0, 0, false>",),
                     "quantize_rne": ("encode_kernel<0, 1, false>",), "dequant": ("dequant_kernel",)}[w]
             if any(x in r["Kernel_Name"] for x in want):
