@@ -312,7 +312,9 @@ def capture_sharded(w, dev, inject_failure=False):
         if inject_failure:
             raise RuntimeError("injected capture failure")
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: with more than one rank the process group's watchdog thread polls events while this thread captures; under the default
+        # (global) capture mode such a call from ANOTHER thread invalidates the capture
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             w.step(None)
     except Exception as e:   # capture not possible here: every rank falls back to eager steps
         ok, graph = False, None

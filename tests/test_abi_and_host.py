@@ -341,6 +341,25 @@ def test_dispatch_cost_model_against_measured_times(golden_dir, fixture, ws, sha
     assert statistics.median(errs) <= (0.07 if ws else 0.12)   # the prices themselves: median |predicted / measured - 1| over every (shape, kernel) pair
 
 
+def test_bench_probe_libraries_link_and_load():
+    """bench.py's measurement probes (tools/libceiling_probe.so, tools/libfloor_probe.so; built by __graft_entry__.build()) load with every symbol resolved
+    and export what bench.py binds.  The floor probe compiles the PRODUCT's ring-kernel source a second time, so a new dependency of that source
+    (round 4: the dispatch's cost model asks the other kernels' envelopes) must be met there too - an unresolved symbol only shows at load time."""
+    import ctypes
+    import subprocess
+    for so, src, deps, syms, flags in (("libceiling_probe.so", "ceiling_probe.hip", [], ["probe_mfma", "probe_read", "probe_abi_version"], []),
+                                       ("libfloor_probe.so", "floor_probe.hip", ["fp8-mps-metal_amd/csrc/fp8mi_gemm.hip", "fp8-mps-metal_amd/csrc/fp8mi_dispatch.h",
+                                                                                 "fp8-mps-metal_amd/csrc/fp8mi_gemm_epi.h"], ["floor_probe_run", "floor_probe_abi_version"],
+                                        ["-fvisibility=hidden", "-std=c++17"])):
+        path, source = os.path.join(ROOT, "tools", so), os.path.join(ROOT, "tools", src)
+        newest = max(os.path.getmtime(f) for f in [source] + [os.path.join(ROOT, d) for d in deps])
+        if not os.path.exists(path) or os.path.getmtime(path) < newest:
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared"] + flags + [source, "-o", path])
+        lib = ctypes.CDLL(path, mode=os.RTLD_NOW)   # RTLD_NOW: every symbol is resolved here, not at the first call
+        for sname in syms:
+            assert hasattr(lib, sname), (so, sname)
+
+
 def test_pad_weight_rows_host_logic():
     """native.pad_weight_rows is plain tensor bookkeeping (no kernel): values and dtype kept, row stride K + pad, 16-byte row
     alignment enforced, pad 0 returns the tensor itself."""

@@ -42,6 +42,10 @@ int fp8mi_cu_count()
 }
 int fp8mi_launch_gemm256(const MMParams &, int, hipStream_t) { return FP8MI_E_UNSUPPORTED; }
 bool fp8mi_gemm256_supported(const MMParams &) { return false; }
+// (fp8mi_gemm.hip's automatic tile choice goes through the dispatch's cost model, which asks the other kernels' envelopes; the probe only launches forced ids)
+bool fp8mi_gemv_supported(const MMParams &) { return false; }
+bool fp8mi_gemv_mx_supported(const MMParams &) { return false; }
+bool fp8mi_skinny_supported(const MMParams &) { return false; }
 
 extern "C" {
 
