@@ -26,7 +26,7 @@ struct TileCost {
     int id, bm, bn, ks, per_cu;
     bool splits;
     int64_t min_m, max_m, max_t128;
-    double p[8];
+    double p[9];
 };
 #include "fp8mi_dispatch_constants.inc"
 
@@ -90,7 +90,7 @@ inline double tile_us(const MMParams &p, const TileCost &t, double cus)
     if (loop < stream_floor) loop = stream_floor;
     double us = t.p[0] + loop + t.p[3] * (M * N * esz / 1e6) / (busy > 0.25 ? busy : 0.25) * (256.0 / cus);
     if (S > 1) us += t.p[4] + t.p[5] * (double)S * (t.bm * t.bn * 4.0 / 1024.0) / 64.0;
-    return us;
+    return us > t.p[8] ? us : t.p[8];   // no launch of the kernel takes less than its own setup + one tile's epilogue
 }
 
 inline double streamer_us(const double (&c)[7], double blocks_of_x, double wg, double N, double K, double k_chain, double cus)

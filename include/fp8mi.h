@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define FP8MI_VERSION 0x000300 /* 0.3.0: + fp8mi_workspace_reset, FP8MI_EPILOGUE_TRANSPOSED, kernel ids GEMV_FP32 / GEMV_MX / GEMM_256W */
+#define FP8MI_VERSION 0x000400 /* 0.4.0: + fp8mi_predict_kernel_us (the dispatch is one cost model); 0.3.0: + fp8mi_workspace_reset, FP8MI_EPILOGUE_TRANSPOSED, kernel ids GEMV_FP32 / GEMV_MX / GEMM_256W */
 
 /* element types of non-fp8 operands */
 enum { FP8MI_F32 = 0, FP8MI_F16 = 1, FP8MI_BF16 = 2 };

@@ -42,7 +42,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_argument_errors_without_gpu(lib):
-    assert lib.fp8mi_version() == 0x000300
+    assert lib.fp8mi_version() == 0x000400
     # argument validation happens before any HIP call, so it is testable here
     rc = lib.fp8mi_scaled_mm(None, None, None, None, None, None, None, 4, 4, 4, 4, 4, 4, 0, 0, 0, 0, 0, None)
     assert rc == -1 and b"NULL" in lib.fp8mi_last_error()
@@ -305,12 +305,14 @@ def test_automatic_dispatch_table():
 
 
 @pytest.mark.parametrize("fixture,ws,shapes,max_110,max_120", [
-    # round 3's raw regret sweeps (seeds 11-22): the hand-written rules this model replaced scored 39 / 6 here (three of the latter the M = 1 rule, kept)
-    ("dispatch_times_r03.json", 1, 1567, 39, 6),
-    # round 4, seeds 31-33 (single measurements, drawn after the model's first fit; the rules: 12 / 1 of 344)
-    ("dispatch_times_r04.json", 1, 356, 22, 3),
-    # round 4, no split-K workspace (a sharded linear's calls, workspace-less callers): never fitted on; the rules: 24 / 21 of 76
-    ("dispatch_times_r04_nows.json", 0, 80, 4, 2)])
+    # (bounds = what the shipped constants score, plus a little slack; in brackets what the hand-written rules of round 3 score on the same data:
+    #  tools/dispatch_fit/compare.py with a library built from 5637f2f)
+    ("dispatch_times_r03.json", 1, 1567, 32, 6),          # round 3's raw regret sweeps, seeds 11-22; fitted on            [rules: 39 / 6 of 1,533]
+    ("dispatch_times_r04.json", 1, 356, 20, 3),           # round 4, seeds 31-33; fitted on                                  [rules: 12 / 1 of 344]
+    ("dispatch_times_r04_ext.json", 1, 517, 20, 3),       # small / ragged dimensions (K, N from 128), seeds 57-60; fitted on [rules: 49 / 35 of 469]
+    ("dispatch_times_r04_heldout.json", 1, 898, 26, 5),   # seeds 51-56 + 61: NEVER fitted on                                [rules: 26 / 6 of 878]
+    ("dispatch_times_r04_nows.json", 0, 370, 11, 4),      # no split-K workspace (a sharded linear's calls); never fitted on [rules: 114 / 99 of 354]
+    ("dispatch_times_r04_ext_nows.json", 0, 100, 10, 5)]) # small / ragged, no workspace; never fitted on                    [rules: 40 / 31 of 91]
 def test_dispatch_cost_model_against_measured_times(golden_dir, fixture, ws, shapes, max_110, max_120):
     """The cost model's choices against MEASURED times (tests/golden/dispatch_times_*.json: every product kernel that takes a shape, timed on MI355X by
     tools/sweep_regret.py).  Regret = time of the kernel the dispatch picks / time of the fastest.  A change to the model or to its constants
@@ -328,6 +330,8 @@ def test_dispatch_cost_model_against_measured_times(golden_dir, fixture, ws, sha
     for M, K, N, out, times in doc["shapes"]:
         oc = L.F32 if out == "f32" else L.BF16
         k = lib.fp8mi_choose_kernel(M, N, K, K, K, N, oc, ws, 0)
+        if k == L.KERNEL_GEMM_256:      # the 8-wave ring kernel stands in below the one-wave-per-SIMD kernels' envelope (K < 256): the sweeps did not time it
+            continue
         assert name.get(k) in times, (M, K, N, out, k)          # the pick is one of the kernels that was measured on the shape
         regrets.append(times[name[k]] / min(times.values()))
         for kn, t in times.items():
@@ -335,10 +339,10 @@ def test_dispatch_cost_model_against_measured_times(golden_dir, fixture, ws, sha
                 us = lib.fp8mi_predict_kernel_us(ids[kn], M, N, K, K, K, N, oc, ws, 0, 256)
                 assert us > 0, (M, K, N, kn)
                 errs.append(abs(us / t - 1.0))
-    assert len(regrets) == shapes
+    assert shapes - 2 <= len(regrets) <= shapes
     assert statistics.median(regrets) <= 1.005
     assert sum(r > 1.10 for r in regrets) <= max_110 and sum(r > 1.20 for r in regrets) <= max_120, (sum(r > 1.10 for r in regrets), sum(r > 1.20 for r in regrets))
-    assert statistics.median(errs) <= (0.07 if ws else 0.12)   # the prices themselves: median |predicted / measured - 1| over every (shape, kernel) pair
+    assert statistics.median(errs) <= (0.08 if ws else 0.12)   # the prices themselves: median |predicted / measured - 1| over every (shape, kernel) pair
 
 
 def test_bench_probe_libraries_link_and_load():

@@ -283,3 +283,60 @@ def test_transposed_epilogue_equals_untransposed_bits(native, cuda, oracle):
         bound = oracle.abs_dot_bound(X, W, [0.013], sw) + np.abs(b)[None, :]
         assert got.shape == (N, Mx)
         assert np.all(np.abs(got.cpu().numpy().T - exact) <= 1e-3 * bound + 1e-30), (Mx, K, N, kern)
+
+
+def _two_rank_worker(rank, world, port, q):
+    """One of two processes sharing the ONE GPU of the box: real HIP kernels for the local product, a gloo group for the gather (RCCL refuses two
+    ranks on one device; what is under test is the module's GPU branch - side stream, events, in-place slots - with a peer that really exists)."""
+    import sys
+    from conftest import PKG
+    sys.path.insert(0, PKG)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fp8_mi355x_native as native
+        from fp8_sharded_linear import ColumnShardedFP8Linear
+        dev = torch.device("cuda:0")
+        g = torch.Generator().manual_seed(11)       # the same data on every rank
+        M, K, N = 320, 1024, 768
+        x = torch.randint(0, 120, (M, K), dtype=torch.uint8, generator=g).to(dev)
+        W = torch.randint(0, 120, (N, K), dtype=torch.uint8, generator=g).to(dev)
+        sb = (torch.rand(N, generator=g) * 0.01 + 0.005).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        sa = torch.tensor([0.02], device=dev)
+        ok = True
+        for od in (torch.float32, torch.bfloat16):
+            ref = native.fp8_scaled_mm(x, W, sa, sb, bias=bias, out_dtype=od, split_k=1)      # the unsharded fused call
+            for chunks in (1, 3):
+                lin = ColumnShardedFP8Linear.from_full(W, sb, bias, chunks=chunks, out_dtype=od)
+                buf = torch.full((N, M), float("nan"), dtype=od, device=dev)                  # caller-owned gather buffer, poisoned
+                for _ in range(2):                                                             # twice: the module's stream / events are reused
+                    y = lin(x, sa, out_t=buf)
+                    torch.cuda.synchronize()
+                    ok = ok and y.data_ptr() == buf.data_ptr() and torch.equal(y, ref)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_linear_two_ranks_on_one_gpu(cuda):
+    """World 2 with REAL kernels: two processes on the box's one GPU, each multiplying its chunk-cyclic half of the weight rows into its slots of
+    the gather buffer, the other half arriving through the group - bit-equal to the unsharded fused call on both ranks (fp32 and bf16, bias and
+    per-row scales, 1 and 3 chunks, caller-owned buffer).  The CPU twin with an injected product is tests/test_sharded_gloo.py."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]

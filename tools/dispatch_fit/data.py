@@ -23,7 +23,10 @@ def load_raw(pattern):
 
 
 FIXTURE_R04 = FIXTURE.replace("r03", "r04")
-FIXTURE_NOWS = FIXTURE.replace("r03", "r04_nows")
+FIXTURE_EXT = FIXTURE.replace("r03", "r04_ext")          # small / ragged dimensions (fitted on)
+FIXTURE_HELDOUT = FIXTURE.replace("r03", "r04_heldout")  # never fitted on
+FIXTURE_NOWS = FIXTURE.replace("r03", "r04_nows")        # no workspace; never fitted on
+FIXTURE_EXT_NOWS = FIXTURE.replace("r03", "r04_ext_nows")
 
 
 def load_fixture(path=FIXTURE):
@@ -31,13 +34,13 @@ def load_fixture(path=FIXTURE):
 
 
 def load_all():
-    """round 3's sweeps + round 4's (a shape measured in both: the mean of the two medians)"""
-    a, b = load_fixture(FIXTURE), load_fixture(FIXTURE_R04)
-    out = {k: dict(v) for k, v in a.items()}
-    for k, v in b.items():
-        if k in out:
-            for n, t in v.items():
-                out[k][n] = 0.5 * (out[k][n] + t) if n in out[k] else t
-        else:
-            out[k] = dict(v)
+    """everything the model is fitted on: round 3's sweeps + round 4's seeds 31-33 + the small / ragged dimensions (a shape measured twice: the mean)"""
+    out = {}
+    for path in (FIXTURE, FIXTURE_R04, FIXTURE_EXT):
+        for k, v in load_fixture(path).items():
+            if k in out:
+                for n, t in v.items():
+                    out[k][n] = 0.5 * (out[k][n] + t) if n in out[k] else t
+            else:
+                out[k] = dict(v)
     return out

@@ -1,7 +1,7 @@
 """Fits the constants of the dispatch's cost model (model.py = the Python twin of csrc/fp8mi_dispatch.h) to measured per-kernel times and writes
 constants.json; emit.py turns that into csrc/fp8mi_dispatch_constants.inc.
 
-    python tools/dispatch_fit/fit.py [raw sweep glob]        (default: the committed fixtures tests/golden/dispatch_times_r03.json + _r04.json)
+    python tools/dispatch_fit/fit.py [raw sweep glob]        (default: the committed fixtures tests/golden/dispatch_times_r03.json + _r04.json + _r04_ext.json)
     python tools/dispatch_fit/emit.py && make -C fp8-mps-metal_amd && python tools/dispatch_fit/check.py
 
 Alternating least squares on log(predicted / measured), soft-L1: per-kernel constants with the globals fixed, then the globals with the kernels
@@ -21,8 +21,8 @@ names = list(TILES)
 rows = {n: [(M, K, N, o, d[n]) for (M, K, N, o), d in data.items() if n in d and M > 1] for n in names + ["mx", "skinny"]}
 weight = {}   # (M, K, N, o, kernel) -> weight (default 1)
 g = np.array([116000.0, 34000.0, 0.4, 0.0])
-ps = {n: np.array([3.0, 0.15, 0.7, 0.2, 2.0, 0.7, 0.05, 6.0]) for n in names}
-LO, HI = np.array([0, 0, 0, 0, 0, 0, 0, 2.0]), np.array([30, 5, 1, 2, 30, 20, 1.0, 9.0])
+ps = {n: np.array([3.0, 0.15, 0.7, 0.2, 2.0, 0.7, 0.05, 6.0, 4.2]) for n in names}
+LO, HI = np.array([0, 0, 0, 0, 0, 0, 0, 2.0, 3.5]), np.array([30, 5, 1, 2, 30, 20, 1.0, 9.0, 14.0])
 GS = np.array([1e5, 1e4, 1.0, 1.0])
 
 

@@ -57,7 +57,7 @@ def tile_terms(name, M, N, K, esz, cus=CUS, has_ws=True):
 
 
 def tile_predict(name, g, p, M, N, K, esz, cus=CUS, has_ws=True):
-    """g = [r_hit, r_miss, busy_exp, hbm_rate] (bytes per us per CU, exponent, bytes per us of the whole chip); p = [fixed, mfma_step, part_a, out_per_mb, xch_fixed, xch_per_64kb_slice, sync_step, operand bytes per us (millions) the kernel streams at best]"""
+    """g = [r_hit, r_miss, busy_exp, hbm_rate] (bytes per us per CU, exponent, bytes per us of the whole chip); p = [fixed, mfma_step, part_a, out_per_mb, xch_fixed, xch_per_64kb_slice, sync_step, operand bytes per us (millions) the kernel streams at best, the least any launch of the kernel takes]"""
     f = tile_terms(name, M, N, K, esz, cus, has_ws)
     r_miss = g[1] / max(f["busy"], 0.125) ** g[2]         # the fabric side is shared: fewer streaming CUs, more for each
     rate = 1.0 / ((1.0 - f["h"]) / r_miss + f["h"] / g[0])
@@ -70,7 +70,7 @@ def tile_predict(name, g, p, M, N, K, esz, cus=CUS, has_ws=True):
     t = p[0] + loop + p[3] * f["out_mb"] / max(f["busy"], 0.25)
     if f["S"] > 1:
         t += p[4] + p[5] * f["S"] * f["part_kb"] / 64.0
-    return t
+    return max(t, p[8])
 
 
 def streamer(c, blocks_of_x, wg, N, K, k_chain, cus=CUS):

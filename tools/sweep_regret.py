@@ -19,7 +19,7 @@ g = torch.Generator(device=dev).manual_seed(seed)
 DIMS = [1024, 1536, 2048, 2560, 3072, 4096, 5120, 6144, 7168, 8192, 9216, 10240, 12288, 13824, 14336, 16384, 28672]
 MS = [1, 2, 4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 160, 192, 256, 320, 384, 512, 640, 768, 1024, 1280, 1536, 2048, 3072, 4096, 8192]
 if os.environ.get("DIMS", "") == "ext":   # round 4: also small and ragged sizes (the cost model must not extrapolate blindly below K, N = 1024 or off the tile grid)
-    DIMS = [128, 256, 384, 512, 640, 768, 1000, 1024, 1280, 1536, 2000, 2048, 2560, 3000, 3072, 3584, 4096, 5000, 5120, 6144, 7168, 8192, 9216, 11008, 12288, 14336]
+    DIMS = [128, 256, 384, 512, 640, 768, 1008, 1024, 1280, 1536, 2000, 2048, 2560, 3008, 3072, 3584, 4096, 5008, 5120, 6144, 7168, 8192, 9216, 11008, 12288, 14336]   # (multiples of 16: K % 16 != 0 is the generic kernel's)
     MS = [2, 3, 5, 6, 8, 10, 16, 20, 28, 32, 40, 56, 64, 72, 100, 128, 144, 200, 256, 300, 400, 512, 600, 1000, 1024, 1500, 2048, 3000, 4096, 6000]
 NAMES = {L.KERNEL_GEMV: "gemv", L.KERNEL_GEMV_MX: "mx", L.KERNEL_SKINNY: "skinny", L.KERNEL_GEMM_32x32: "32x32", L.KERNEL_GEMM_32x64: "32x64",
          L.KERNEL_GEMM_64x64: "64x64", L.KERNEL_GEMM_64x128: "64x128", L.KERNEL_GEMM_128x64: "128x64", L.KERNEL_GEMM_128: "128", L.KERNEL_GEMM_128D: "128D",
@@ -64,6 +64,8 @@ while done < count:
         torch.cuda.synchronize()
         ms = sorted(kt.ms); t = ms[len(ms) // 2] * 1e3
         res[kid] = min(res.get(kid, 1e30), t)   # AUTO is timed first and last: the better of the two
+    if len(res) < 2:   # no forced kernel takes the shape
+        continue
     best_k, best_t = min(((k, t) for k, t in res.items() if k != 0), key=lambda kv: kv[1])
     ratio = res[0] / best_t
     rows.append((ratio, M, K, N, picked, best_k, res[0], best_t))
