@@ -18,9 +18,12 @@ s1 = torch.full((1,), 0.01, device=dev)
 g = torch.Generator(device=dev).manual_seed(seed)
 DIMS = [1024, 1536, 2048, 2560, 3072, 4096, 5120, 6144, 7168, 8192, 9216, 10240, 12288, 13824, 14336, 16384, 28672]
 MS = [1, 2, 4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 160, 192, 256, 320, 384, 512, 640, 768, 1024, 1280, 1536, 2048, 3072, 4096, 8192]
+if os.environ.get("MS"):
+    MS = [int(v) for v in os.environ["MS"].split(",")]
 if os.environ.get("DIMS", "") == "ext":   # round 4: also small and ragged sizes (the cost model must not extrapolate blindly below K, N = 1024 or off the tile grid)
     DIMS = [128, 256, 384, 512, 640, 768, 1008, 1024, 1280, 1536, 2000, 2048, 2560, 3008, 3072, 3584, 4096, 5008, 5120, 6144, 7168, 8192, 9216, 11008, 12288, 14336]   # (multiples of 16: K % 16 != 0 is the generic kernel's)
-    MS = [2, 3, 5, 6, 8, 10, 16, 20, 28, 32, 40, 56, 64, 72, 100, 128, 144, 200, 256, 300, 400, 512, 600, 1000, 1024, 1500, 2048, 3000, 4096, 6000]
+    if not os.environ.get("MS"):
+        MS = [2, 3, 5, 6, 8, 10, 16, 20, 28, 32, 40, 56, 64, 72, 100, 128, 144, 200, 256, 300, 400, 512, 600, 1000, 1024, 1500, 2048, 3000, 4096, 6000]
 NAMES = {L.KERNEL_GEMV: "gemv", L.KERNEL_GEMV_MX: "mx", L.KERNEL_SKINNY: "skinny", L.KERNEL_GEMM_32x32: "32x32", L.KERNEL_GEMM_32x64: "32x64",
          L.KERNEL_GEMM_64x64: "64x64", L.KERNEL_GEMM_64x128: "64x128", L.KERNEL_GEMM_128x64: "128x64", L.KERNEL_GEMM_128: "128", L.KERNEL_GEMM_128D: "128D",
          L.KERNEL_GEMM_256W: "256W", L.KERNEL_GEMM_256x128W: "256x128W"}
@@ -31,7 +34,8 @@ def candidates(M, K, N):
     if M == 1: ks.append(L.KERNEL_GEMV)
     if 2 <= M <= 8: ks.append(L.KERNEL_GEMV_MX)
     if 2 <= M <= 64: ks.append(L.KERNEL_SKINNY)
-    if M <= 192: ks += [L.KERNEL_GEMM_32x32, L.KERNEL_GEMM_32x64, L.KERNEL_GEMM_64x64, L.KERNEL_GEMM_64x128]
+    if M <= 256: ks += [L.KERNEL_GEMM_32x32, L.KERNEL_GEMM_32x64]          # (round 4: the small tiles up to M = 256 / 512 - one round of 64x64 tiles against a shallow K beats
+    if M <= 512: ks += [L.KERNEL_GEMM_64x64, L.KERNEL_GEMM_64x128]         #  half a round of 128x64: M=256 K=N=4096 9.9 against 13.4 us)
     if M > 1: ks += [L.KERNEL_GEMM_128x64, L.KERNEL_GEMM_128]
     if M > 64 and ((M + 127) // 128) * ((N + 127) // 128) <= 640: ks.append(L.KERNEL_GEMM_128D)
     if M > 128: ks += [L.KERNEL_GEMM_256x128W]
