@@ -27,6 +27,9 @@ FIXTURE_EXT = FIXTURE.replace("r03", "r04_ext")          # small / ragged dimens
 FIXTURE_HELDOUT = FIXTURE.replace("r03", "r04_heldout")  # never fitted on
 FIXTURE_NOWS = FIXTURE.replace("r03", "r04_nows")        # no workspace; never fitted on
 FIXTURE_EXT_NOWS = FIXTURE.replace("r03", "r04_ext_nows")
+FIXTURE_MIDM = FIXTURE.replace("r03", "r04_midm")        # 200 <= M <= 1024 with the small tiles offered (fitted on)
+FIXTURE_MIDM_NOWS = FIXTURE.replace("r03", "r04_midm_nows")
+FIXTURE_ANCHORS = FIXTURE.replace("r03", "r04_anchors")  # the BASELINE configs, bench.py's workloads and their neighbours, three repeats (fitted on, weighted)
 
 
 def load_fixture(path=FIXTURE):
@@ -34,9 +37,9 @@ def load_fixture(path=FIXTURE):
 
 
 def load_all():
-    """everything the model is fitted on: round 3's sweeps + round 4's seeds 31-33 + the small / ragged dimensions (a shape measured twice: the mean)"""
+    """everything the model is fitted on: round 3's sweeps + round 4's seeds 31-33 + the small / ragged dimensions + the mid-M sweeps (a shape measured twice: the mean)"""
     out = {}
-    for path in (FIXTURE, FIXTURE_R04, FIXTURE_EXT):
+    for path in (FIXTURE, FIXTURE_R04, FIXTURE_EXT, FIXTURE_MIDM, FIXTURE_ANCHORS):
         for k, v in load_fixture(path).items():
             if k in out:
                 for n, t in v.items():
