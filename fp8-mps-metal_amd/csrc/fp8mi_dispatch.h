@@ -1,8 +1,8 @@
 // The automatic dispatch of fp8mi_scaled_mm as ONE cost model (round 4; host-only arithmetic, exported as fp8mi_choose_kernel /
-// fp8mi_predict_kernel_us and tested on the CPU against measured times: tests/test_abi_and_host.py, tests/golden/dispatch_times_r03.json).
+// fp8mi_predict_kernel_us and tested on the CPU against measured times: tests/test_abi_and_host.py, tests/golden/dispatch_times_cold_*.json).
 //
 // Every kernel that takes the problem gets a predicted time in microseconds; the cheapest runs.  The forms are physical, the constants are
-// FITTED (tools/dispatch_fit/, on the raw output of tools/sweep_regret.py: 1,567 shapes x every product kernel on MI355X) and live in
+// FITTED (tools/dispatch_fit/, on the output of tools/sweep_regret.py: 3,871 shapes x every product kernel on MI355X, cold weights) and live in
 // fp8mi_dispatch_constants.inc:
 //   tile kernels   t = fixed + max(rounds x K-steps x step, operand bytes / best streaming rate) + C bytes + split-K exchange
 //                  step   = max(matrix pipe, global -> LDS stream) + sync, both shared by the workgroups co-resident on a CU

@@ -276,7 +276,7 @@ int fp8mi_choose_kernel(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ld
 /* The dispatch's cost model itself (round 4; host-only): the time in microseconds it predicts for `kernel` on this problem on a device of
  * `compute_units` CUs (0 = the current device's), or a negative value when the kernel does not take the problem or is not offered for it
  * (FP8MI_KERNEL_GEMV / _GENERIC / _AUTO are not priced: M = 1 is a rule, the generic kernel the last resort).  fp8mi_choose_kernel returns
- * the id with the smallest prediction.  For tests (tests/golden/dispatch_times_r03.json) and for callers that log the dispatch. */
+ * the id with the smallest prediction.  For tests (tests/golden/dispatch_times_cold_*.json) and for callers that log the dispatch. */
 double fp8mi_predict_kernel_us(int kernel, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int out_dtype,
                                int has_workspace, int split_k, int compute_units);
 

@@ -16,7 +16,7 @@ IDS = {"mx": L.KERNEL_GEMV_MX, "skinny": L.KERNEL_SKINNY, "32x32": L.KERNEL_GEMM
        "64x128": L.KERNEL_GEMM_64x128, "128x64": L.KERNEL_GEMM_128x64, "128": L.KERNEL_GEMM_128, "128D": L.KERNEL_GEMM_128D,
        "256W": L.KERNEL_GEMM_256W, "256x128W": L.KERNEL_GEMM_256x128W, "gemv": L.KERNEL_GEMV}
 NAMES = {v: k for k, v in IDS.items()}
-for path, ws in ((data.FIXTURE, 1), (data.FIXTURE_R04, 1), (data.FIXTURE_EXT, 1), (data.FIXTURE_MIDM, 1), (data.FIXTURE_HELDOUT, 1), (data.FIXTURE_NOWS, 0), (data.FIXTURE_EXT_NOWS, 0), (data.FIXTURE_MIDM_NOWS, 0)):
+for path, ws in ((data.FIXTURE_FIT, 1), (data.FIXTURE_ANCHORS, 1), (data.FIXTURE_HELDOUT, 1), (data.FIXTURE_NOWS, 0)):
     d = data.load_fixture(path)
     for tag, lib in libs:
         r, miss = [], 0

@@ -1,10 +1,17 @@
 """Measured per-kernel times the dispatch's cost model is fitted on: either the raw output of tools/sweep_regret.py (gpurun_out/, scratch) or the
-committed fixture made from it (tests/golden/dispatch_times_r03.json: median over the repeats of a shape)."""
+committed fixtures made from it by make_fixture.py (tests/golden/dispatch_times_cold_*.json: median over the repeats of a shape)."""
 import glob, json, os, re, statistics
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-FIXTURE = os.path.join(ROOT, "tests", "golden", "dispatch_times_r03.json")
+G = os.path.join(ROOT, "tests", "golden")
+# round 4, COLD weights (>= 320 MiB in rotation for every shape; tools/r4_cold.sh).  The sweeps of round 3 and of the first half of round 4 capped the rotation at
+# 16 buffers: every weight matrix below 16 MiB was timed resident in the Infinity Cache - they are retired (git history: dispatch_times_r03.json, _r04*.json)
+FIXTURE_FIT = os.path.join(G, "dispatch_times_cold_fit.json")          # fitted on
+FIXTURE_ANCHORS = os.path.join(G, "dispatch_times_cold_anchors.json")  # BASELINE configs, bench workloads and neighbours: fitted on, 6x weight
+FIXTURE_HELDOUT = os.path.join(G, "dispatch_times_cold_heldout.json")  # never fitted on
+FIXTURE_NOWS = os.path.join(G, "dispatch_times_cold_nows.json")        # no workspace; never fitted on
+FIXTURE = FIXTURE_FIT
 LINE = re.compile(r"^M=\s*(\d+) K=\s*(\d+) N=\s*(\d+): auto\((\w+)\)\s+([\d.]+)\s+(.*?)\s+\| auto/best")
 
 
@@ -22,24 +29,14 @@ def load_raw(pattern):
     return {k: {n: statistics.median(v) for n, v in d.items()} for k, d in data.items()}
 
 
-FIXTURE_R04 = FIXTURE.replace("r03", "r04")
-FIXTURE_EXT = FIXTURE.replace("r03", "r04_ext")          # small / ragged dimensions (fitted on)
-FIXTURE_HELDOUT = FIXTURE.replace("r03", "r04_heldout")  # never fitted on
-FIXTURE_NOWS = FIXTURE.replace("r03", "r04_nows")        # no workspace; never fitted on
-FIXTURE_EXT_NOWS = FIXTURE.replace("r03", "r04_ext_nows")
-FIXTURE_MIDM = FIXTURE.replace("r03", "r04_midm")        # 200 <= M <= 1024 with the small tiles offered (fitted on)
-FIXTURE_MIDM_NOWS = FIXTURE.replace("r03", "r04_midm_nows")
-FIXTURE_ANCHORS = FIXTURE.replace("r03", "r04_anchors")  # the BASELINE configs, bench.py's workloads and their neighbours, three repeats (fitted on, weighted)
-
-
 def load_fixture(path=FIXTURE):
     return {(M, K, N, out): times for M, K, N, out, times in json.load(open(path))["shapes"]}
 
 
 def load_all():
-    """everything the model is fitted on: round 3's sweeps + round 4's seeds 31-33 + the small / ragged dimensions + the mid-M sweeps (a shape measured twice: the mean)"""
+    """everything the model is fitted on (a shape measured in both files: the mean)"""
     out = {}
-    for path in (FIXTURE, FIXTURE_R04, FIXTURE_EXT, FIXTURE_MIDM, FIXTURE_ANCHORS):
+    for path in (FIXTURE_FIT, FIXTURE_ANCHORS):
         for k, v in load_fixture(path).items():
             if k in out:
                 for n, t in v.items():

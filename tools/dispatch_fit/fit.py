@@ -1,7 +1,7 @@
 """Fits the constants of the dispatch's cost model (model.py = the Python twin of csrc/fp8mi_dispatch.h) to measured per-kernel times and writes
 constants.json; emit.py turns that into csrc/fp8mi_dispatch_constants.inc.
 
-    python tools/dispatch_fit/fit.py [raw sweep glob]        (default: the committed fixtures tests/golden/dispatch_times_r03.json + _r04.json + _r04_ext.json)
+    python tools/dispatch_fit/fit.py [raw sweep glob]        (default: the committed fixtures tests/golden/dispatch_times_cold_fit.json + _cold_anchors.json)
     python tools/dispatch_fit/emit.py && make -C fp8-mps-metal_amd && python tools/dispatch_fit/check.py
 
 Alternating least squares on log(predicted / measured), soft-L1: per-kernel constants with the globals fixed, then the globals with the kernels

@@ -19,4 +19,8 @@ case ${1:-a} in
     for s in 127 128 129 130; do run heldout$s -- $s 140; done
     run heldout_ext131 DIMS=ext -- 131 120; run heldout_midm132 MS=200,256,320,384,448,512,640,768,1024 -- 132 110
     run nows123 NOWS=1 -- 123 120; run nows124 NOWS=1 -- 124 120; run nows_ext125 NOWS=1 DIMS=ext -- 125 100; run nows_midm126 NOWS=1 MS=200,256,320,384,512,768,1024 -- 126 90 ;;
+ d) for s in 133 134 135 136 137 138 139 140 141 142; do run std$s -- $s 140; done
+    for s in 143 144 145; do run ext$s DIMS=ext -- $s 130; done
+    run midm146 MS=200,224,256,288,320,384,448,512,640,768,896,1024 -- 146 130; run midm147 MS=200,256,300,320,384,400,512,600,768,1000,1024 DIMS=ext -- 147 120; run midm148 MS=256,384,512,768,1024 -- 148 120
+    run f32_149 OUT=f32 -- 149 120; run f32_150 OUT=f32 MS=200,256,384,512,768,1024 -- 150 100 ;;
 esac
