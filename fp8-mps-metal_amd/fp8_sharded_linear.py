@@ -40,6 +40,11 @@ Why it shards this way (MI355X-first):
     side stream and the per-chunk events live in the module, so a forward is
     `chunks` launches + `chunks` collectives and can be captured into a HIP graph.
 
+  * The gather itself has two forms.  `gather="rccl"` (default): `dist.all_gather_into_tensor`, in place.  `gather="peer"`:
+    the direct all-gather of include/fp8mi_peer.h - every rank stores its slab into all peers' buffers at once (all 7
+    xGMI links busy, no ring), three kernel launches on the side stream and no RCCL call; the gather buffer then belongs
+    to the module (IPC-mapped on every peer) and the result is a view of it, valid until the next forward.
+
 One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).  The
 local product is the HIP kernel; `mm` can be injected so that the sharding /
 gather logic is testable with gloo on CPU (tests only - the product default
@@ -82,7 +87,7 @@ class ColumnShardedFP8Linear:
     """
 
     def __init__(self, weight_u8, scale_b, bias=None, *, N: int, group=None, chunks: int = 1,
-                 out_dtype=torch.bfloat16, mm=None):
+                 out_dtype=torch.bfloat16, mm=None, gather: str = "rccl", max_tokens: int | None = None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -108,6 +113,11 @@ class ColumnShardedFP8Linear:
         self._bias = [None if self.bias is None else self.bias[j * self.nc:(j + 1) * self.nc] for j in range(chunks)]
         self._comm_stream = None
         self._events = None
+        if gather not in ("rccl", "peer"):
+            raise ValueError(f"gather must be 'rccl' or 'peer', not {gather!r}")
+        if gather == "peer" and self.world < 2:
+            raise ValueError("gather='peer' needs a process group of at least 2 ranks")
+        self.gather, self.max_tokens, self._peer = gather, max_tokens, None
 
     @classmethod
     def from_full(cls, weight_u8_full, scale_b, bias=None, *, group=None, chunks=1, **kw):
@@ -122,6 +132,25 @@ class ColumnShardedFP8Linear:
         b = None if bias is None else bias.reshape(-1)[rows]
         return cls(weight_u8_full[rows].contiguous(), sb, b, N=N, group=group, chunks=chunks, **kw)
 
+    def _peer_buffer(self, M: int, dev) -> torch.Tensor:
+        """gather='peer': the module's IPC-mapped gather buffer as the contiguous (N, M) C^T.  Created at the first forward
+        (a collective: every rank gets here together) for max(M, max_tokens) tokens."""
+        import fp8_peer_gather
+        esz = torch.empty(0, dtype=self.out_dtype).element_size()
+        if self._peer is None:
+            self._peer = fp8_peer_gather.PeerGather(self.N * max(M, self.max_tokens or 0) * esz, dev, group=self.group)
+        if self.N * M * esz > self._peer.nbytes:
+            raise ValueError(f"gather='peer': {M} tokens exceed the buffer made for {self._peer.nbytes // (self.N * esz)} (pass max_tokens)")
+        if (self.nc * M * esz) % 16:
+            raise ValueError(f"gather='peer': a slab of {self.nc} x {M} {self.out_dtype} elements is not a multiple of 16 bytes")
+        return self._peer.tensor(self.out_dtype)[:self.N * M].view(self.N, M)
+
+    def close(self):
+        """gather='peer': unmap and free the gather buffer (collective).  Nothing to do for 'rccl'."""
+        if self._peer is not None:
+            self._peer.close()
+            self._peer = None
+
     def forward(self, x_u8: torch.Tensor, scale_a: torch.Tensor, out_t: torch.Tensor | None = None) -> torch.Tensor:
         """x_u8 (M,K) uint8 replicated on every rank -> (M,N) `out_dtype`
         (a transposed view of the gathered (N,M) buffer), identical on every rank.
@@ -130,7 +159,14 @@ class ColumnShardedFP8Linear:
         serving loop can ping-pong two buffers); the returned tensor is its `.t()` view."""
         M = x_u8.shape[0]
         dev = x_u8.device
-        if out_t is None:
+        peer = self.gather == "peer"
+        if peer:
+            if out_t is not None:
+                raise ValueError("gather='peer' owns its gather buffer: do not pass out_t")
+            if dev.type != "cuda":
+                raise ValueError("gather='peer' needs the operands on a HIP device")
+            out_t = self._peer_buffer(M, dev)
+        elif out_t is None:
             out_t = torch.empty(self.N, M, dtype=self.out_dtype, device=dev)  # C^T
         elif not (out_t.shape == (self.N, M) and out_t.dtype == self.out_dtype and out_t.device == dev and out_t.is_contiguous()):
             raise ValueError(f"out_t must be a contiguous ({self.N}, {M}) {self.out_dtype} tensor on {dev}")
@@ -151,6 +187,9 @@ class ColumnShardedFP8Linear:
             if on_gpu:
                 self._events[j].record(cur)
                 self._comm_stream.wait_event(self._events[j])
+                if peer:                                               # slab -> the same bytes of every peer's buffer
+                    self._peer.allgather(slot.data_ptr() - out_t.data_ptr(), slot.numel() * slot.element_size(), self._comm_stream.cuda_stream)
+                    continue
                 with torch.cuda.stream(self._comm_stream):
                     dist.all_gather_into_tensor(block, slot, group=self.group)   # in place: slot is block[rank]
             else:

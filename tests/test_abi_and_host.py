@@ -64,6 +64,52 @@ def test_version_and_argument_errors_without_gpu(lib):
     assert lib.fp8mi_scaled_mm_workspace_bytes() >= 4096 + 256 * 128 * 64 * 4
 
 
+def test_peer_library_exports_what_its_header_declares_and_validates_arguments():
+    """include/fp8mi_peer.h (the direct all-gather): every declared entry point exported and bound by the Python host; the argument checks
+    that precede any HIP call.  The data path needs peers: tests/test_gpu_patch.py::test_peer_allgather_three_ranks_on_one_gpu."""
+    so = os.path.join(PKG, "libfp8mi_peer.so")
+    srcs = [os.path.join(PKG, "csrc", "peer", "fp8mi_peer.hip"), os.path.join(ROOT, "include", "fp8mi_peer.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["make", "-C", PKG, "-s", "libfp8mi_peer.so"])
+    import fp8_peer_gather
+    lib = fp8_peer_gather.load()
+    text = re.sub(r"/\*.*?\*/", "", open(srcs[1]).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(fp8mi_peer_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) == 11 and "fp8mi_peer_allgather" in names
+    for n in names:
+        fn = getattr(lib, n)                                   # AttributeError = declared but not exported
+        assert fn.restype is not None, n
+        assert n in ("fp8mi_peer_version", "fp8mi_peer_last_error") or fn.argtypes is not None, f"{n} has no ctypes signature"
+    assert lib.fp8mi_peer_version() == 0x000100
+    vp = ctypes.c_void_p
+    two = (vp * 2)(16, 32)
+    ctx = vp()
+    assert lib.fp8mi_peer_ctx_create(1, 0, two, two, 4096, ctypes.byref(ctx)) == -2 and b"world" in lib.fp8mi_peer_last_error()
+    assert lib.fp8mi_peer_ctx_create(2, 2, two, two, 4096, ctypes.byref(ctx)) == -2
+    assert lib.fp8mi_peer_ctx_create(2, 0, two, two, 4100, ctypes.byref(ctx)) == -2 and b"multiple of 16" in lib.fp8mi_peer_last_error()
+    assert lib.fp8mi_peer_ctx_create(2, 0, (vp * 2)(16, 0), two, 4096, ctypes.byref(ctx)) == -1
+    assert lib.fp8mi_peer_ctx_create(2, 0, None, two, 4096, ctypes.byref(ctx)) == -1
+    assert lib.fp8mi_peer_allgather(None, 0, 16, 0, None) == -1
+    assert lib.fp8mi_peer_alloc(16, 0, None) == -1 and lib.fp8mi_peer_export(None, None) == -1 and lib.fp8mi_peer_open(None, None) == -1
+    assert lib.fp8mi_peer_free(None) == 0 and lib.fp8mi_peer_close(None) == 0
+
+
+def test_peer_gather_host_refuses_what_it_cannot_do(monkeypatch):
+    import fp8_peer_gather
+    from fp8_sharded_linear import ColumnShardedFP8Linear
+    with pytest.raises(fp8_peer_gather.PeerGatherError, match="process group"):
+        fp8_peer_gather.PeerGather(4096, torch.device("cuda:0"))
+    w = torch.zeros(8, 16, dtype=torch.uint8)
+    with pytest.raises(ValueError, match="at least 2 ranks"):
+        ColumnShardedFP8Linear(w, torch.ones(1), N=8, gather="peer")
+    with pytest.raises(ValueError, match="'rccl' or 'peer'"):
+        ColumnShardedFP8Linear(w, torch.ones(1), N=8, gather="ring")
+    monkeypatch.setattr(fp8_peer_gather, "_lib", None)
+    monkeypatch.setattr(fp8_peer_gather.os.path, "exists", lambda p: False)
+    with pytest.raises(ImportError, match="libfp8mi_peer.so"):
+        fp8_peer_gather.load()
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     import fp8_mi355x_lib
     monkeypatch.setattr(fp8_mi355x_lib, "_lib", None)

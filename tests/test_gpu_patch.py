@@ -340,3 +340,103 @@ def test_sharded_linear_two_ranks_on_one_gpu(cuda):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def _peer_gather_worker(rank, world, port, q):
+    """One of `world` processes on the box's ONE GPU: the direct all-gather of include/fp8mi_peer.h with peers that really exist (HIP IPC maps
+    another process's allocation whichever device it lives on; what a single box cannot show is the xGMI rate)."""
+    import sys
+    from conftest import PKG
+    sys.path.insert(0, PKG)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok, note = True, ""
+    try:
+        import fp8_mi355x_native as native
+        import fp8_peer_gather
+        from fp8_sharded_linear import ColumnShardedFP8Linear
+        dev = torch.device("cuda:0")
+        # 1. raw slabs: a pattern per (rank, round), slabs of two sizes, 24 rounds back to back without a host sync in between
+        slab = 3 * 4096 + 16
+        pg = fp8_peer_gather.PeerGather(world * slab, dev, timeout_us=20_000_000)
+        buf = pg.tensor(torch.uint8)
+        snaps = []
+        for it in range(24):
+            n = slab if it % 2 == 0 else 4096
+            buf[rank * slab:rank * slab + n] = (rank * 37 + it * 11 + torch.arange(n, device=dev)) % 251
+            pg.allgather(rank * slab, n)
+            snaps.append((it, n, buf.clone()))        # stream-ordered behind the gather: what a consumer would read
+        if pg.status() != 0:
+            ok, note = False, "status after raw rounds"
+        for it, n, snap in snaps:
+            for r in range(world):
+                want = ((r * 37 + it * 11 + torch.arange(n)) % 251).to(torch.uint8)
+                if not torch.equal(snap[r * slab:r * slab + n].cpu(), want):
+                    ok, note = False, f"raw round {it} slab of rank {r}"
+        # 2. argument errors are errors
+        for bad in ((8, 16), (0, 24), (world * slab, 16)):
+            try:
+                pg.allgather(*bad)
+                ok, note = False, f"accepted {bad}"
+            except fp8_peer_gather.PeerGatherError:
+                pass
+        pg.close()
+        # 3. a peer that never arrives: bounded waits, status bits instead of a hung GPU
+        pg = fp8_peer_gather.PeerGather(4096, dev, timeout_us=300_000)
+        if rank == 0:
+            pg.allgather(0, 1024)
+            st = pg.status()
+            if st != (fp8_peer_gather.TIMEOUT_READY | fp8_peer_gather.TIMEOUT_DONE):
+                ok, note = False, f"timeout status {st}"
+            if pg.status() != 0:
+                ok, note = False, "status not cleared"
+        pg.close()
+        # 4. the sharded linear on it: bit-equal to the unsharded fused call, fresh activations every forward (a stale slab would show)
+        g = torch.Generator().manual_seed(13)
+        M, K, N = 320, 1024, 768
+        W = torch.randint(0, 120, (N, K), dtype=torch.uint8, generator=g).to(dev)
+        sb = (torch.rand(N, generator=g) * 0.01 + 0.005).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        sa = torch.tensor([0.02], device=dev)
+        for od, chunks in ((torch.float32, 1), (torch.bfloat16, 2)):
+            lin = ColumnShardedFP8Linear.from_full(W, sb, bias, chunks=chunks, out_dtype=od, gather="peer", max_tokens=M)
+            for it in range(6):
+                Mi = M if it % 3 else M - 64                      # fewer tokens than the buffer was made for
+                x = torch.randint(0, 120, (Mi, K), dtype=torch.uint8, generator=g).to(dev)
+                y = lin(x, sa)
+                ref = native.fp8_scaled_mm(x, W, sa, sb, bias=bias, out_dtype=od, split_k=1)
+                if not torch.equal(y, ref):
+                    ok, note = False, f"sharded linear {od} chunks {chunks} forward {it}"
+            if lin._peer.status() != 0:
+                ok, note = False, "status after the sharded linear"
+            lin.close()
+    except Exception as e:        # noqa: BLE001 - reported through the queue; the parent asserts
+        ok, note = False, f"{type(e).__name__}: {e}"
+    finally:
+        q.put((rank, ok, note))
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_peer_allgather_three_ranks_on_one_gpu(cuda):
+    """include/fp8mi_peer.h end to end with three processes sharing the box's GPU: IPC export / open, the ready -> push -> done protocol over 24
+    unsynchronised rounds, argument errors, the bounded wait (a rank that never calls: status bits, no hang) and ColumnShardedFP8Linear(gather=
+    'peer') bit-equal to the unsharded call."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    procs = [ctx.Process(target=_peer_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(r, True, "") for r in range(world)], res
