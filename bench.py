@@ -119,8 +119,9 @@ TARGET_STEP_S = 0.016   # a step lasts >= 16 ms: the driver's 20 steps time >= 0
 class Workload:
     """One named workload: buffers + a `launch(i)` closure calling the C ABI."""
 
-    def __init__(self, name, dev, world=1, rank=0, kernel=L.KERNEL_AUTO, nbuf=None, sharded=False):
+    def __init__(self, name, dev, world=1, rank=0, kernel=L.KERNEL_AUTO, nbuf=None, sharded=False, gather="rccl"):
         self.name, self.dev, self.world, self.rank, self.kernel = name, dev, world, rank, kernel
+        self.peer = None
         self.sharded = sharded or world > 1
         self.lib = L.load()
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -153,7 +154,10 @@ class Workload:
                 # chunk-cyclic rows, all-gather of chunk j on a side stream under the GEMM of chunk j+1
                 from fp8_sharded_linear import ColumnShardedFP8Linear
                 self.chunks = 2   # per-call RCCL latency vs overlap: 2 row chunks per rank
-                self.linears = [ColumnShardedFP8Linear(B, self.sb, None, N=N, chunks=self.chunks, out_dtype=self.out_dtype)
+                if gather == "peer":   # ONE IPC-mapped gather buffer for every weight buffer's linear (include/fp8mi_peer.h)
+                    import fp8_peer_gather
+                    self.peer = fp8_peer_gather.PeerGather(N * M * esz, dev)
+                self.linears = [ColumnShardedFP8Linear(B, self.sb, None, N=N, chunks=self.chunks, out_dtype=self.out_dtype, peer=self.peer)
                                 for B in self.Bs]
                 self.Cs = [torch.empty(Nl, M, dtype=self.out_dtype, device=dev) for _ in range(2)]
             else:
@@ -329,7 +333,8 @@ def capture_sharded(w, dev, inject_failure=False):
 def time_steps(w, steps, warmup, use_graph, world, n_streams=1):
     dev = w.dev
     graph = None
-    if (use_graph and w.sharded and dist.is_initialized() and dist.get_backend() == "nccl"
+    # (capturable: RCCL collectives, and the peer-store gather - plain kernel launches whose epoch lives in device memory; not gloo's host staging)
+    if (use_graph and w.sharded and dist.is_initialized() and (dist.get_backend() == "nccl" or w.peer is not None)
             and os.environ.get("FP8MI_BENCH_SHARDED_GRAPH", "1") == "1"):
         graph = capture_sharded(w, dev)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 and not w.sharded else None
@@ -950,6 +955,107 @@ def host_kernarg_child(steps, warmup):
         return {"error": repr(e)}
 
 
+LAUNCHER_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME",
+                "MASTER_ADDR", "MASTER_PORT", "NCCL_DEBUG_FILE", "NCCL_ASYNC_ERROR_HANDLING", "TORCH_NCCL_ASYNC_ERROR_HANDLING")
+
+
+def peer_store_child(n, steps, warmup, dry=False):
+    """`peer_allgather` on the N > 1 line: the sharded FLUX step gathered by the direct all-gather of include/fp8mi_peer.h (every rank stores its
+    slab into all peers at once) next to the same step gathered by RCCL, measured by a SEPARATE group of N ranks that rank 0 starts and waits for
+    BEFORE this process has touched the GPU (the other ranks of this run wait in their rendezvous meanwhile).  Separate processes on purpose:
+    the peer-store path has only ever run with several ranks on ONE GPU (tests/test_gpu_patch.py) - no multi-GPU node was available to the build -
+    so whatever it does on a real xGMI fabric (a fault included) must not be able to take the headline measurement down with it."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), "--peer-child", "--gpus", str(n), "--steps", str(max(3, steps // 2)), "--warmup", str(max(1, warmup // 2))]
+    if dry:
+        return {"launch": cmd}
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_ENV and not k.startswith("TORCHELASTIC")}
+    env.update(FP8MI_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+        for ln in reversed(out.stdout.splitlines()):
+            if ln.lstrip().startswith('{"peer_allgather"'):
+                return json.loads(ln)["peer_allgather"]
+        return {"error": f"the child group printed no line (rc {out.returncode}): {out.stderr[-400:]}"}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+def peer_gather_only(w, reps=10):
+    """The peer-store gather alone, slabs of the sharded linear's chunk size (the counterpart of allgather_only)."""
+    dev, world = w.dev, w.world
+    nc = w.N // w.chunks
+    nbytes = nc * w.M * torch.empty(0, dtype=w.out_dtype).element_size()
+    off = w.rank * nbytes
+    for _ in range(3):
+        w.peer.allgather(off, nbytes)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        w.peer.allgather(off, nbytes)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    t = torch.tensor([e0.elapsed_time(e1) * 1e3 / reps], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    us = float(t.item())
+    recv = (world - 1) * nbytes
+    return {"calls_per_linear": w.chunks, "bytes_received_per_call": recv, "avg_us_per_call": round(us, 2), "launches_per_call": 3,
+            "ingress_GBs_per_rank": round(recv / (us * 1e-6) / 1e9, 1), "GBs_per_link": round(nbytes / (us * 1e-6) / 1e9, 1)}
+
+
+def peer_child_main(args):
+    """One rank of the group peer_store_child() starts: the sharded FLUX step with gather = the process group's all-gather, then with the
+    peer-store all-gather - same weights, same chunks, same timing harness - and whether the two return the same bits."""
+    world, rank, local = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("FP8MI_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", local % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    with stdout_to_stderr():
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+        t0 = torch.zeros(1, device=dev)
+        dist.all_reduce(t0)
+        torch.cuda.synchronize(dev)
+    L.load()
+    out = {"ranks": world, "backend": "rccl" if backend == "nccl" else backend, "workload": "flux, N-column-sharded, 2 chunks per rank (as the headline of this line)"}
+    ref = None
+    for key, gather in (("collective", "rccl"), ("peer_store", "peer")):
+        entry = {}
+        try:
+            w = Workload("flux", dev, world, rank, gather=gather)
+            dt, graphed = time_steps(w, args.steps, args.warmup, True, world)
+            launches = args.steps * w.inner
+            entry = {"value": round(w.flops * world * launches / dt / 1e12, 3), "unit": "TFLOP/s", "ms_per_step": round(dt / args.steps * 1e3, 5),
+                     "us_per_linear": round(dt / launches * 1e6, 2), "linears_per_step": w.inner, "hip_graph": graphed}
+            y = w.linears[0](w.A, w.sa)
+            torch.cuda.synchronize(dev)
+            if gather == "rccl":
+                ref = y.clone()
+                entry["gather_only"] = allgather_only(w)
+            else:
+                same = torch.tensor([1 if (ref is not None and torch.equal(y, ref)) else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                entry["bit_equal_to_collective_on_every_rank"] = bool(same.item())
+                entry["gather_only"] = peer_gather_only(w)
+                st = torch.tensor([w.peer.status()], dtype=torch.int32, device=dev)
+                dist.all_reduce(st, op=dist.ReduceOp.MAX)
+                entry["timeout_status"] = int(st.item())   # 0: every bounded wait was met
+                w.peer.close()
+            del w
+            torch.cuda.empty_cache()
+        except Exception as e:
+            entry["error"] = repr(e)
+        out[key] = entry
+    if rank == 0:
+        print(json.dumps({"peer_allgather": out}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -971,6 +1077,8 @@ def main():
     ap.add_argument("--no-host-kernarg", action="store_true", help="skip secondary.gemm_host_kernarg (a child process that runs C3 with kernel arguments in host memory)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearse the multi-GPU code path (sharded linear + RCCL all-gather) with a 1-rank group")
+    ap.add_argument("--peer-child", action="store_true", help="internal: one rank of the group that measures the peer-store all-gather (peer_store_child)")
+    ap.add_argument("--no-peer-store", action="store_true", help="N > 1: skip the separate group that measures the peer-store all-gather")
     ap.add_argument("--dry-launch", action="store_true",
                     help="with --gpus N > 1 and no WORLD_SIZE: print the torch.distributed.run command bench.py would start, as JSON, and exit")
     args = ap.parse_args()
@@ -985,8 +1093,15 @@ def main():
         print(json.dumps({"launch": None, "note": "nothing to launch: --gpus 1, or WORLD_SIZE is set (a launcher is already around bench.py)"}))
         return
 
+    if args.peer_child:
+        return peer_child_main(args)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    peer_store = None
+    if (world > 1 and rank == 0 and args.workload in ("auto", "flux") and not args.no_secondary and not args.no_peer_store
+            and os.environ.get("FP8MI_BENCH_CHILD") != "1"):
+        peer_store = {"skipped": "under a profiler preload: no child processes"} if under_profiler() else peer_store_child(world, args.steps, args.warmup)
     host_kernarg = None
     if (world == 1 and args.workload == "auto" and not args.no_secondary and not args.force_sharded and not args.no_host_kernarg
             and os.environ.get("FP8MI_BENCH_CHILD") != "1" and os.environ.get("HIP_FORCE_DEV_KERNARG") == "1"):
@@ -1076,6 +1191,8 @@ def main():
         line["device_uuids"] = comm_report.get("device_uuids")
     if same_workload_1gpu is not None:
         line["same_workload_on_one_gpu"] = same_workload_1gpu
+    if peer_store is not None:
+        line["peer_allgather"] = peer_store
     if "cpu_baseline" in res:
         line["cpu_baseline"] = res["cpu_baseline"]
     if ceilings is not None:

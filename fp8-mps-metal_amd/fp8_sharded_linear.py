@@ -84,10 +84,14 @@ class ColumnShardedFP8Linear:
     scale_b   : [1] or [N/world] (per local row, same order)
     bias      : None or [N/world] (same order)
     mm        : tests only - `mm(w_rows, x_u8, scale_w, scale_x, bias_or_None, out)` filling `out` (rows, M)
+    gather    : "rccl" (default) or "peer" (module docstring); max_tokens sizes the module's own peer buffer;
+    peer      : an existing fp8_peer_gather.PeerGather to gather through (implies gather="peer"): layers whose outputs are
+                consumed one after the other can share ONE mapped buffer - the protocol orders a rank's next slab behind its
+                peers' consumers of the previous one
     """
 
     def __init__(self, weight_u8, scale_b, bias=None, *, N: int, group=None, chunks: int = 1,
-                 out_dtype=torch.bfloat16, mm=None, gather: str = "rccl", max_tokens: int | None = None):
+                 out_dtype=torch.bfloat16, mm=None, gather: str = "rccl", max_tokens: int | None = None, peer=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -113,11 +117,13 @@ class ColumnShardedFP8Linear:
         self._bias = [None if self.bias is None else self.bias[j * self.nc:(j + 1) * self.nc] for j in range(chunks)]
         self._comm_stream = None
         self._events = None
+        if peer is not None:
+            gather = "peer"
         if gather not in ("rccl", "peer"):
             raise ValueError(f"gather must be 'rccl' or 'peer', not {gather!r}")
         if gather == "peer" and self.world < 2:
             raise ValueError("gather='peer' needs a process group of at least 2 ranks")
-        self.gather, self.max_tokens, self._peer = gather, max_tokens, None
+        self.gather, self.max_tokens, self._peer, self._own_peer = gather, max_tokens, peer, peer is None
 
     @classmethod
     def from_full(cls, weight_u8_full, scale_b, bias=None, *, group=None, chunks=1, **kw):
@@ -147,9 +153,9 @@ class ColumnShardedFP8Linear:
 
     def close(self):
         """gather='peer': unmap and free the gather buffer (collective).  Nothing to do for 'rccl'."""
-        if self._peer is not None:
+        if self._peer is not None and self._own_peer:
             self._peer.close()
-            self._peer = None
+        self._peer = None
 
     def forward(self, x_u8: torch.Tensor, scale_a: torch.Tensor, out_t: torch.Tensor | None = None) -> torch.Tensor:
         """x_u8 (M,K) uint8 replicated on every rank -> (M,N) `out_dtype`

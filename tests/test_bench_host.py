@@ -42,6 +42,37 @@ def test_dry_launch_under_a_launcher_starts_nothing():
     assert json.loads(out.stdout.strip().splitlines()[-1])["launch"] is None
 
 
+def test_peer_store_child_group_command_and_its_clean_environment(monkeypatch):
+    """The separate group of ranks that measures the peer-store all-gather on an N > 1 line: a torch.distributed.run child of its own, on a port
+    of its own, carrying none of the launcher variables of the run that starts it (it would otherwise join the parent's rendezvous)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    d = bench.peer_store_child(8, 20, 5, dry=True)
+    cmd = d["launch"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--peer-child", "--gpus", "8", "--steps", "10", "--warmup", "2"]
+    seen = {}
+
+    class Done:
+        returncode, stderr = 0, ""
+        stdout = 'noise\n{"peer_allgather": {"ranks": 8, "peer_store": {"value": 1.0}}}\n'
+
+    def fake_run(cmd, env, **kw):
+        seen.update(env=env, kw=kw)
+        return Done()
+    import subprocess as sp
+    monkeypatch.setattr(sp, "run", fake_run)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        monkeypatch.setenv(k, "7")
+    assert bench.peer_store_child(8, 20, 5) == {"ranks": 8, "peer_store": {"value": 1.0}}
+    assert not any(k in seen["env"] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID"))
+    assert seen["env"]["FP8MI_BENCH_CHILD"] == "1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert seen["kw"]["timeout"] <= 480      # shorter than the 10 minutes the other ranks' rendezvous waits for rank 0
+    Done.stdout = "no line here\n"
+    assert "error" in bench.peer_store_child(8, 20, 5)
+
+
 def test_nccl_debug_log_summary():
     import bench
     log = "\n".join([
