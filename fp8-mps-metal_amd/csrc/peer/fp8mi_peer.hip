@@ -97,15 +97,18 @@ __global__ __launch_bounds__(256) void peer_push_kernel(PeerTab t, int64_t offse
     const u32x4 *src = (const u32x4 *)(t.data[t.rank] + offset);
     uint8_t *dst = t.data[p] + offset;
     const int64_t pieces = bytes >> 4;
-    // four loads in flight per lane, then their four stores (posted: nothing waits for them until the wave ends)
+    // kDepth 16-byte loads in flight per lane, then their stores (posted: nothing waits for them until the wave ends).  Few, deep blocks on purpose: the
+    // push shares the GPU with the NEXT chunk's GEMM, whose one-wave-per-SIMD tiles need a CU's whole register file - a push wave resident on a
+    // CU keeps such a tile off it, so the copy is confined to a few dozen CUs and gets its bytes in flight from depth, not from width
+    constexpr int kDepth = 16;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pieces; i += 4 * stride) {
-        u32x4 v[4];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pieces; i += kDepth * stride) {
+        u32x4 v[kDepth];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < kDepth; ++u)
             if (i + u * stride < pieces) v[u] = src[i + u * stride];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < kDepth; ++u)
             if (i + u * stride < pieces) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst + ((i + u * stride) << 4)), "v"(v[u]) : "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -236,8 +239,11 @@ int fp8mi_peer_allgather(fp8mi_peer_ctx *ctx, int64_t offset, int64_t bytes, int
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(peer_begin_kernel, dim3(1), dim3(64), 0, s, ctx->tab);
     if (bytes > 0) {
-        int bx = ctx->push_blocks > 0 ? ctx->push_blocks : (int)((bytes + 65535) / 65536);
-        bx = bx < 1 ? 1 : bx > 64 ? 64 : bx;
+        // blocks per peer: one per 512 KiB of slab, at most 12 (FP8MI_PEER_BLOCKS overrides, up to 64).  One block moves ~45 GB/s of same-device copy
+        // (tools/time_peer_gather.py, profiles/r04_peer_rehearsal.txt); a link takes 153 GB/s; 7 peers x 12 blocks leave two thirds of the CUs to the GEMM
+        int bx = ctx->push_blocks > 0 ? ctx->push_blocks : (int)((bytes + (1 << 19) - 1) >> 19);
+        const int cap = ctx->push_blocks > 0 ? 64 : 12;
+        bx = bx < 1 ? 1 : bx > cap ? cap : bx;
         hipLaunchKernelGGL(peer_push_kernel, dim3(bx, ctx->tab.world - 1), dim3(256), 0, s, ctx->tab, offset, bytes, ticks);
     }
     hipLaunchKernelGGL(peer_end_kernel, dim3(1), dim3(64), 0, s, ctx->tab, ticks);
