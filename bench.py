@@ -1005,7 +1005,7 @@ def peer_gather_only(w, reps=10):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     us = float(t.item())
     recv = (world - 1) * nbytes
-    return {"calls_per_linear": w.chunks, "bytes_received_per_call": recv, "avg_us_per_call": round(us, 2), "launches_per_call": 3,
+    return {"calls_per_linear": w.chunks, "bytes_received_per_call": recv, "avg_us_per_call": round(us, 2), "launches_per_call": 2,
             "ingress_GBs_per_rank": round(recv / (us * 1e-6) / 1e9, 1), "GBs_per_link": round(nbytes / (us * 1e-6) / 1e9, 1)}
 
 

@@ -1,5 +1,5 @@
 // libfp8mi_peer.so: the direct (peer-store) all-gather of the sharded linear's output - see include/fp8mi_peer.h for
-// the contract.  Three small kernels per call; every wait is bounded by the device's wall clock.
+// the contract.  Two small kernels per call; every wait is bounded by the device's wall clock.
 //
 // Memory model notes (gfx950, 8 XCDs with private L2s):
 //   * flag blocks are UNCACHED device memory (hipDeviceMallocUncached): a peer's store is visible to the owner's next
@@ -71,24 +71,20 @@ __device__ bool wait_flag(const uint32_t *p, uint32_t e, int64_t ticks)
     }
 }
 
-// begin: the next epoch; every peer learns that this rank's earlier consumers are behind it on the stream
-__global__ __launch_bounds__(64) void peer_begin_kernel(PeerTab t)
-{
-    uint32_t *mine = t.flags[t.rank];
-    const uint32_t e = flag_load(mine + kEpoch) + 1u;   // every lane reads the old value before lane 0 replaces it (one wave: in order)
-    const int p = threadIdx.x;
-    if (p < t.world && p != t.rank) flag_store(t.flags[p] + kReady + t.rank, e);
-    if (p == 0) flag_store(mine + kEpoch, e);
-}
-
-// push: blockIdx.y picks the peer (rank r starts with r+1: at every moment the ranks store to different peers), blockIdx.x a share of the slab
+// The epoch of a call is (own counter + 1); the counter is device-resident (kernel arguments would be frozen by a graph capture) and is advanced
+// by the call's `end` kernel, so both kernels of a call read the same value.
+//
+// push: blockIdx.y picks the peer (rank r starts with r+1: at every moment the ranks store to different peers), blockIdx.x a share of the slab.
+// Block (0, y) first tells its peer "rank r is ready to receive epoch e" - this kernel is behind the rank's consumers of the previous gather on
+// the stream - then every block of the row waits for the same word from the peer.  (With bytes == 0 the grid is (1, world-1): the handshake only.)
 __global__ __launch_bounds__(256) void peer_push_kernel(PeerTab t, int64_t offset, int64_t bytes, int64_t ticks)
 {
     __shared__ int go;
     uint32_t *mine = t.flags[t.rank];
     const int p = (t.rank + 1 + (int)blockIdx.y) % t.world;
     if (threadIdx.x == 0) {
-        const uint32_t e = flag_load(mine + kEpoch);
+        const uint32_t e = flag_load(mine + kEpoch) + 1u;
+        if (blockIdx.x == 0) flag_store(t.flags[p] + kReady + t.rank, e);
         go = wait_flag(mine + kReady + p, e, ticks);
         if (!go) atomicOr(mine + kStatus, FP8MI_PEER_TIMEOUT_READY);
     }
@@ -114,16 +110,17 @@ __global__ __launch_bounds__(256) void peer_push_kernel(PeerTab t, int64_t offse
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// end: this rank's slab has landed everywhere (the push kernel is behind us on the stream); wait for everybody else's
+// end: this rank's slab has landed everywhere (the push kernel precedes this one on the stream); wait for everybody else's; advance the epoch
 __global__ __launch_bounds__(64) void peer_end_kernel(PeerTab t, int64_t ticks)
 {
     uint32_t *mine = t.flags[t.rank];
-    const uint32_t e = flag_load(mine + kEpoch);
+    const uint32_t e = flag_load(mine + kEpoch) + 1u;   // one wave: every lane has read the counter before lane 0 replaces it below
     const int p = threadIdx.x;
     if (p < t.world && p != t.rank) {
         flag_store(t.flags[p] + kDone + t.rank, e);
         if (!wait_flag(mine + kDone + p, e, ticks)) atomicOr(mine + kStatus, FP8MI_PEER_TIMEOUT_DONE);
     }
+    if (p == 0) flag_store(mine + kEpoch, e);
 }
 
 }  // namespace
@@ -237,13 +234,12 @@ int fp8mi_peer_allgather(fp8mi_peer_ctx *ctx, int64_t offset, int64_t bytes, int
     if (timeout_us <= 0) timeout_us = 30ll * 1000 * 1000;
     const int64_t ticks = timeout_us * ctx->wall_khz / 1000;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(peer_begin_kernel, dim3(1), dim3(64), 0, s, ctx->tab);
-    if (bytes > 0) {
+    {
         // blocks per peer: one per 512 KiB of slab, at most 12 (FP8MI_PEER_BLOCKS overrides, up to 64).  One block moves ~45 GB/s of same-device copy
         // (tools/time_peer_gather.py, profiles/r04_peer_rehearsal.txt); a link takes 153 GB/s; 7 peers x 12 blocks leave two thirds of the CUs to the GEMM
         int bx = ctx->push_blocks > 0 ? ctx->push_blocks : (int)((bytes + (1 << 19) - 1) >> 19);
         const int cap = ctx->push_blocks > 0 ? 64 : 12;
-        bx = bx < 1 ? 1 : bx > cap ? cap : bx;
+        bx = (bx < 1 || bytes == 0) ? 1 : bx > cap ? cap : bx;
         hipLaunchKernelGGL(peer_push_kernel, dim3(bx, ctx->tab.world - 1), dim3(256), 0, s, ctx->tab, offset, bytes, ticks);
     }
     hipLaunchKernelGGL(peer_end_kernel, dim3(1), dim3(64), 0, s, ctx->tab, ticks);

@@ -5,7 +5,7 @@ One `PeerGather` per gather buffer.  Every rank (one process per GPU) allocates 
 data buffer of the same size and a flag block through libfp8mi_peer.so, the HIP IPC
 handles travel through `torch.distributed`'s object all-gather (any backend: this is
 setup, 128 bytes per rank), every rank maps its peers' allocations, and from then on
-`allgather(offset, nbytes)` is three kernel launches on the caller's stream with no
+`allgather(offset, nbytes)` is two kernel launches on the caller's stream with no
 host involvement and no RCCL call (include/fp8mi_peer.h describes the protocol and
 its bounded waits).  The reference has nothing to compare with (one GPU, one command
 queue: fp8_bridge.cpp:67); inside this build it is the alternative to

@@ -42,7 +42,7 @@ Why it shards this way (MI355X-first):
 
   * The gather itself has two forms.  `gather="rccl"` (default): `dist.all_gather_into_tensor`, in place.  `gather="peer"`:
     the direct all-gather of include/fp8mi_peer.h - every rank stores its slab into all peers' buffers at once (all 7
-    xGMI links busy, no ring), three kernel launches on the side stream and no RCCL call; the gather buffer then belongs
+    xGMI links busy, no ring), two kernel launches on the side stream and no RCCL call; the gather buffer then belongs
     to the module (IPC-mapped on every peer) and the result is a view of it, valid until the next forward.
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).  The

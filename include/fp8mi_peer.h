@@ -12,13 +12,14 @@
  *     (uncached device memory), both allocated here and exported as HIP IPC handles; the host exchanges the
  *     handles (64 bytes each) any way it likes (the Python host uses torch.distributed's object all-gather) and
  *     opens the peers';
- *   - fp8mi_peer_allgather enqueues three small kernels on the caller's stream:
- *       begin : epoch e = ++own epoch (device-resident, so a captured HIP graph replays correctly); tell every peer
- *               "rank r is ready to receive epoch e" (its earlier consumers precede this kernel in stream order);
- *       push  : for each peer p (a different first peer on every rank), wait until p is ready for e, then store this
- *               rank's slab [offset, offset+bytes) of its own buffer to the same range of p's buffer (system-scope,
- *               written through);
- *       end   : tell every peer "rank r's slab of epoch e has landed", then wait until every peer has said so.
+ *   - fp8mi_peer_allgather enqueues two small kernels on the caller's stream (the call's epoch e = own counter + 1; the
+ *     counter is device-resident, so a captured HIP graph replays correctly):
+ *       push  : for each peer p (a different first peer on every rank): tell p "rank r is ready to receive epoch e"
+ *               (the rank's earlier consumers precede this kernel in stream order), wait until p is ready for e, then
+ *               store this rank's slab [offset, offset+bytes) of its own buffer to the same range of p's buffer
+ *               (system-scope, written through);
+ *       end   : tell every peer "rank r's slab of epoch e has landed", wait until every peer has said so, advance
+ *               the counter.
  *     Work enqueued behind it on the same stream sees the whole gathered buffer;
  *   - every wait is BOUNDED (timeout_us of the device's wall clock): a peer that never arrives sets a bit in the
  *     status word instead of hanging the GPU; fp8mi_peer_status reads it.

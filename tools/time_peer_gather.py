@@ -58,7 +58,7 @@ def main():
     res = dict(q.get(timeout=600) for _ in range(world))
     for p in ps:
         p.join(60)
-    print(f"# peer-store all-gather alone: {world} processes on one GPU, slab {slab >> 20} MiB per rank; us per call (3 launches) on rank 0 / max over ranks,")
+    print(f"# peer-store all-gather alone: {world} processes on one GPU, slab {slab >> 20} MiB per rank; us per call (2 launches) on rank 0 / max over ranks,")
     print("# GB/s per peer = slab / time (each rank pushes its slab to world-1 peers at once)")
     for i, (blocks, _) in enumerate(res[0]):
         worst = max(res[r][i][1] for r in range(world))
