@@ -115,7 +115,7 @@ class PeerGather:
             _check(lib.fp8mi_peer_ctx_create(self.world, self.rank, dptr, fptr, self.nbytes, ctypes.byref(ctx)), "fp8mi_peer_ctx_create")
             self._ctx = ctx.value
             self._bytes = torch.as_tensor(_DeviceBytes(self._data, self.nbytes), device=self.device)
-        dist.barrier(group=group)      # nobody pushes before everybody has mapped everybody
+            dist.barrier(group=group)      # nobody pushes before everybody has mapped everybody
 
     def tensor(self, dtype: torch.dtype = torch.uint8) -> torch.Tensor:
         """This rank's gather buffer as a flat tensor of `dtype` (a view of the library's allocation: valid until close())."""
