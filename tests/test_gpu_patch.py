@@ -412,6 +412,19 @@ def _peer_gather_worker(rank, world, port, q):
             if lin._peer.status() != 0:
                 ok, note = False, "status after the sharded linear"
             lin.close()
+        # 5. two layers through ONE mapped buffer (what bench.py's sharded workload does with its rotating weight buffers): the second layer's slabs
+        #    must not land before the first layer's result has been consumed on every rank
+        shared = fp8_peer_gather.PeerGather(N * M * 4, dev, timeout_us=20_000_000)
+        W2 = torch.randint(0, 120, (N, K), dtype=torch.uint8, generator=g).to(dev)
+        lins = [ColumnShardedFP8Linear.from_full(w_, sb, bias, chunks=2, out_dtype=torch.float32, peer=shared) for w_ in (W, W2)]
+        x = torch.randint(0, 120, (M, K), dtype=torch.uint8, generator=g).to(dev)
+        outs = [lins[i % 2](x, sa).clone() for i in range(6)]          # (the clone is the consumer: stream-ordered behind the gather)
+        refs = [native.fp8_scaled_mm(x, w_, sa, sb, bias=bias, out_dtype=torch.float32, split_k=1) for w_ in (W, W2)]
+        if not all(torch.equal(o, refs[i % 2]) for i, o in enumerate(outs)) or shared.status() != 0:
+            ok, note = False, "two layers sharing one peer buffer"
+        for l_ in lins:
+            l_.close()                                                   # (does not own the buffer)
+        shared.close()
     except Exception as e:        # noqa: BLE001 - reported through the queue; the parent asserts
         ok, note = False, f"{type(e).__name__}: {e}"
     finally:
