@@ -549,7 +549,7 @@ def measure_floor(w, launches=128):
       empty_launch_us   the kernel returns behind its argument loads (same grid, block and LDS allocation)
       c_store_only_us   no K loop: launch, arguments, tile map, the fused epilogue's store of the whole C, kernel end
       dma_only_us       the K loop's LDS-DMA stream with its waits and barriers, no fragment reads, no MFMAs (+ everything above)
-    The real kernel hides its MFMAs and fragment reads under that stream (DESIGN.md 6.3), so dma_only_us is this design's attainable floor."""
+    The real kernel hides its MFMAs and fragment reads under that stream (DESIGN.md 8), so dma_only_us is this design's attainable floor."""
     if w.name not in FLOOR_IDS or w.sharded:
         return None
     try:

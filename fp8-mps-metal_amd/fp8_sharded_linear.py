@@ -48,7 +48,7 @@ Why it shards this way (MI355X-first):
 One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).  The
 local product is the HIP kernel; `mm` can be injected so that the sharding /
 gather logic is testable with gloo on CPU (tests only - the product default
-has no CPU path).  No 2/4/8-GPU measurement exists yet (DESIGN.md 7).
+has no CPU path).  No 2/4/8-GPU measurement exists yet (DESIGN.md 9).
 """
 
 from __future__ import annotations
