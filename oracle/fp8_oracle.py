@@ -261,7 +261,8 @@ def dequantize_f16(u8, scale=1.0):
     (fp8_matmul.metal:215-223, fp8_mps_native.py:114-122)."""
     h = decode(u8).astype(np.float16)  # exact: every e4m3 value fits fp16
     s = np.float16(np.float32(scale))
-    return (h * s).astype(np.float16)
+    with np.errstate(over="ignore"):      # a product beyond 65504 IS inf in fp16, as in the reference's torch multiply
+        return (h * s).astype(np.float16)
 
 
 def quantize(x):
