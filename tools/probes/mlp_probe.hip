@@ -30,7 +30,7 @@ __global__ __launch_bounds__(W * 64) void mlp(const uint8_t *hot, const uint8_t 
     const unsigned long long pb = (unsigned long long)(src + (size_t)blockIdx.x * wg_stride);
     u32x4 rpf = {(uint32_t)pb, (uint32_t)(pb >> 32) & 0xFFFFu, span, 0x00020000u};
     rpf[0] = __builtin_amdgcn_readfirstlane(rpf[0]); rpf[1] = __builtin_amdgcn_readfirstlane(rpf[1]); rpf[2] = __builtin_amdgcn_readfirstlane(rpf[2]);
-    uint32_t sink = 0;
+    uint32_t sink = 0, ssink = 0;
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
@@ -41,12 +41,23 @@ __global__ __launch_bounds__(W * 64) void mlp(const uint8_t *hot, const uint8_t 
             const uint32_t off = (uint32_t)wave * q + ((j * 1024u) & (q - 1)) + (uint32_t)(lane & 7) * 128u;
             asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(sink) : "v"(off), "s"(rpf) : "memory");
         }
+        if (MIX == 3 && (it & 3) == 0) {   // the same lines, touched through the SCALAR cache path instead (s_load: K$ -> L2, not the CU's vector L1):
+            // per 4 iterations one cold KiB = 8 lines is due, PFD x 32 iterations ahead; wave-uniform address, the loaded dword is never read
+            const uint32_t j = (uint32_t)it + 32u * PFD + 3u;
+            const unsigned long long a = pb + (unsigned long long)((uint32_t)wave * q + ((j * 1024u) & (q - 1)));
+            const uint32_t alo = __builtin_amdgcn_readfirstlane((uint32_t)a), ahi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+            const unsigned long long au = ((unsigned long long)ahi << 32) | alo;
+            asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x80\n\ts_load_dword %0, %1, 0x100\n\ts_load_dword %0, %1, 0x180\n\t"
+                         "s_load_dword %0, %1, 0x200\n\ts_load_dword %0, %1, 0x280\n\ts_load_dword %0, %1, 0x300\n\ts_load_dword %0, %1, 0x380"
+                         : "+s"(ssink) : "s"(au) : "memory");
+        }
         if (MIX && (it & 3) != 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, dst, 16, voff, (uint32_t)wave * (262144u / W) + (((uint32_t)it * 1024u) & (262144u / W - 1)), 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, soff, 0, 0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1 + (MIX == 2 ? 1 : 0)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1 + (MIX == 2 ? 1 : 0)) : "memory");   // (the scalar prefetches count in lgkmcnt: nothing waits for them)
     }
     asm volatile("" ::"v"(sink));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("" ::"s"(ssink));
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
@@ -64,7 +75,8 @@ static void run(const Case &c, const uint8_t *hot, const uint8_t *buf, size_t bu
         const uint8_t *base = buf + (c.rotate ? (size_t)(r % (int)(buf_bytes / need)) * need : 0);
         hipEventRecord(e0);
         const int iters = c.iters * 4 / W;
-        if (c.mix == 2) hipLaunchKernelGGL((mlp<DEPTH, 2, W, PFD>), dim3(blocks), dim3(W * 64), 0, 0, hot, base, c.wg_stride, c.span, iters, d_cyc);
+        if (c.mix == 3) hipLaunchKernelGGL((mlp<DEPTH, 3, W, PFD>), dim3(blocks), dim3(W * 64), 0, 0, hot, base, c.wg_stride, c.span, iters, d_cyc);
+        else if (c.mix == 2) hipLaunchKernelGGL((mlp<DEPTH, 2, W, PFD>), dim3(blocks), dim3(W * 64), 0, 0, hot, base, c.wg_stride, c.span, iters, d_cyc);
         else if (c.mix) hipLaunchKernelGGL((mlp<DEPTH, 1, W, PFD>), dim3(blocks), dim3(W * 64), 0, 0, hot, base, c.wg_stride, c.span, iters, d_cyc);
         else hipLaunchKernelGGL((mlp<DEPTH, 0, W, PFD>), dim3(blocks), dim3(W * 64), 0, 0, hot, base, c.wg_stride, c.span, iters, d_cyc);
         hipEventRecord(e1); hipEventSynchronize(e1);
@@ -79,7 +91,7 @@ static void run(const Case &c, const uint8_t *hot, const uint8_t *buf, size_t bu
     }
     const double bytes_wg = (double)W * (c.iters * 4 / W) * 1024.0;
     printf("%-34s %d waves, depth %2d (%4d lines in flight per CU)%s: %6.1f B/clk/CU (median CU, in-kernel cycles)  chip %6.2f TB/s  %8.1f us\n", c.name, W, DEPTH, W * DEPTH * 8,
-           c.mix == 2 ? (PFD == 1 ? ", prefetch 1 block ahead" : PFD == 2 ? ", prefetch 2 blocks ahead" : ", prefetch 4 blocks ahead") : "",
+           c.mix == 3 ? (PFD == 1 ? ", SCALAR prefetch 1 block ahead" : PFD == 2 ? ", SCALAR prefetch 2 blocks ahead" : ", SCALAR prefetch 4 blocks ahead") : c.mix == 2 ? (PFD == 1 ? ", prefetch 1 block ahead" : PFD == 2 ? ", prefetch 2 blocks ahead" : ", prefetch 4 blocks ahead") : "",
            bytes_wg / med, bytes_wg * blocks / (best * 1e-3) / 1e12, best * 1e3);
 }
 
@@ -107,5 +119,10 @@ int main()
     run<4, 4, 2>(mixpf, hot, buf, buf_bytes, d_cyc, blocks); run<8, 4, 2>(mixpf, hot, buf, buf_bytes, d_cyc, blocks); run<16, 4, 2>(mixpf, hot, buf, buf_bytes, d_cyc, blocks);
     run<8, 4, 1>(mixpf, hot, buf, buf_bytes, d_cyc, blocks); run<8, 4, 4>(mixpf, hot, buf, buf_bytes, d_cyc, blocks); run<16, 4, 4>(mixpf, hot, buf, buf_bytes, d_cyc, blocks);
     run<8, 8, 2>(mixpf, hot, buf, buf_bytes, d_cyc, blocks); run<16, 8, 2>(mixpf, hot, buf, buf_bytes, d_cyc, blocks);
+    // the same, the cold lines touched through the scalar cache path (s_load_dword, one per 128-byte line)
+    const Case mixsp = {"3 : 1 L2 : HBM + scalar prefetch", (size_t)4 << 20, 4u << 20, 1024, true, 3};
+    run<4, 4, 2>(mixsp, hot, buf, buf_bytes, d_cyc, blocks); run<8, 4, 2>(mixsp, hot, buf, buf_bytes, d_cyc, blocks); run<16, 4, 2>(mixsp, hot, buf, buf_bytes, d_cyc, blocks);
+    run<8, 4, 1>(mixsp, hot, buf, buf_bytes, d_cyc, blocks); run<8, 4, 4>(mixsp, hot, buf, buf_bytes, d_cyc, blocks); run<16, 4, 4>(mixsp, hot, buf, buf_bytes, d_cyc, blocks);
+    run<8, 8, 2>(mixsp, hot, buf, buf_bytes, d_cyc, blocks); run<16, 8, 2>(mixsp, hot, buf, buf_bytes, d_cyc, blocks);
     return 0;
 }
