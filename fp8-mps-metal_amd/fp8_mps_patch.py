@@ -124,17 +124,22 @@ def _metal_scaled_mm(input, other, *args, out_dtype=None, scale_a=None, scale_b=
         scale_a = _ones(dev)
     if scale_b is None:
         scale_b = _ones(dev)
+    # The kernels' fused epilogue writes float32 / float16 / bfloat16.  The reference ends in `result.to(out_dtype)` for ANY dtype
+    # (fp8_mps_patch.py:103-104) - a float8_e4m3fn result then goes through its patched `.to`, i.e. the encode kernel: same here, as a
+    # second launch behind the float32 product.
+    final = None
+    if out_dtype is not None and out_dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        final, out_dtype = out_dtype, torch.float32
     # other is (K,N); the kernels want the (N,K) row-major operand.  For the column-major `other` torch mandates the
     # storage IS that operand: pointers and strides go down as they are - no uint8 views, no .t() (each a tensor
     # construction of ~1 us on a path whose kernels take 5-15 us)
     r = native.scaled_mm_colmajor(input, other, scale_a, scale_b, bias=bias, scale_result=scale_result, out_dtype=out_dtype)
-    if r is not None:
-        return r
-    # any other layout (row-major `other`, strided rows): the general entry makes the operands contiguous
-    a = input if input.dtype == torch.uint8 else input.view(torch.uint8)
-    o = other if other.dtype == torch.uint8 else other.view(torch.uint8)
-    return native.fp8_scaled_mm_auto(a, o.t(), scale_a, scale_b, bias=bias, scale_result=scale_result,
-                                     out_dtype=out_dtype)
+    if r is None:
+        # any other layout (row-major `other`, strided rows): the general entry makes the operands contiguous
+        a = input if input.dtype == torch.uint8 else input.view(torch.uint8)
+        o = other if other.dtype == torch.uint8 else other.view(torch.uint8)
+        r = native.fp8_scaled_mm_auto(a, o.t(), scale_a, scale_b, bias=bias, scale_result=scale_result, out_dtype=out_dtype)
+    return r if final is None else _metal_tensor_to(r, final)
 
 
 _ones_cache = {}

@@ -152,6 +152,21 @@ def test_patched_scaled_mm(patch, native, cuda, oracle):
     assert np.all(np.abs(out.cpu().numpy() - exp) <= 1e-3 * bnd)  # MFMA_TOL
 
 
+def test_patched_scaled_mm_any_out_dtype(patch, native, cuda, oracle):
+    """The reference ends `_scaled_mm` in `result.to(out_dtype)` whatever the dtype (fp8_mps_patch.py:103-104): a float8_e4m3fn result goes through
+    its patched `.to` - the encode kernel with the reference's rounding rules - and float64 through torch."""
+    g = torch.Generator().manual_seed(8)
+    Aq, sa = native.fp8_quantize(torch.randn(48, 256, generator=g).to(cuda))
+    Bq, sb = native.fp8_quantize(torch.randn(64, 256, generator=g).to(cuda))
+    sr = torch.tensor([0.37], device=cuda)
+    f32 = torch._scaled_mm(Aq.view(F8), Bq.view(F8).t(), scale_a=sa, scale_b=sb, scale_result=sr)
+    out = torch._scaled_mm(Aq.view(F8), Bq.view(F8).t(), scale_a=sa, scale_b=sb, scale_result=sr, out_dtype=F8)
+    assert out.dtype == F8 and out.shape == (48, 64) and out.device.type == "cuda"
+    assert np.array_equal(out.view(torch.uint8).cpu().numpy(), oracle.encode(f32.cpu().numpy()))       # byte-exact: the reference's encoder on the fp32 result
+    out = torch._scaled_mm(Aq.view(F8), Bq.view(F8).t(), sa, sb, None, sr, torch.float64)                # positional, torch's order
+    assert out.dtype == torch.float64 and torch.equal(out, f32.double())
+
+
 def test_fp8_linear_call_site_flux_shapes(patch, native, cuda, oracle):
     """A ComfyUI-style fp8 linear (x.to(fp8) -> _scaled_mm(w.t()) -> bf16) at a
     FLUX projection shape, unchanged call site."""
