@@ -977,7 +977,7 @@ def peer_store_child(n, steps, warmup, dry=False):
     env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_ENV and not k.startswith("TORCHELASTIC")}
     env.update(FP8MI_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     try:
-        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)   # (the other ranks of this run wait in their rendezvous, whose own limit is 10 minutes)
         for ln in reversed(out.stdout.splitlines()):
             if ln.lstrip().startswith('{"peer_allgather"'):
                 return json.loads(ln)["peer_allgather"]
