@@ -959,6 +959,9 @@ LAUNCHER_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_R
                 "MASTER_ADDR", "MASTER_PORT", "NCCL_DEBUG_FILE", "NCCL_ASYNC_ERROR_HANDLING", "TORCH_NCCL_ASYNC_ERROR_HANDLING")
 
 
+PEER_CHILD_TIMEOUT_S = 300   # the other ranks of the run wait in their rendezvous meanwhile, whose own limit is 10 minutes
+
+
 def peer_store_child(n, steps, warmup, dry=False):
     """`peer_allgather` on the N > 1 line: the sharded FLUX step gathered by the direct all-gather of include/fp8mi_peer.h (every rank stores its
     slab into all peers at once) next to the same step gathered by RCCL, measured by a SEPARATE group of N ranks that rank 0 starts and waits for
@@ -977,11 +980,20 @@ def peer_store_child(n, steps, warmup, dry=False):
     env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_ENV and not k.startswith("TORCHELASTIC")}
     env.update(FP8MI_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     try:
-        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)   # (the other ranks of this run wait in their rendezvous, whose own limit is 10 minutes)
-        for ln in reversed(out.stdout.splitlines()):
+        # its own session = its own process group: on a timeout the launcher AND its ranks are killed (exactly the group started here), so that
+        # nothing of it is left on the GPUs when the headline measurement begins
+        import signal
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            stdout, stderr = proc.communicate(timeout=PEER_CHILD_TIMEOUT_S)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.communicate()
+            return {"error": f"the child group did not finish within {PEER_CHILD_TIMEOUT_S} s and was killed"}
+        for ln in reversed(stdout.splitlines()):
             if ln.lstrip().startswith('{"peer_allgather"'):
                 return json.loads(ln)["peer_allgather"]
-        return {"error": f"the child group printed no line (rc {out.returncode}): {out.stderr[-400:]}"}
+        return {"error": f"the child group printed no line (rc {proc.returncode}): {stderr[-400:]}"}
     except Exception as e:
         return {"error": repr(e)}
 

@@ -54,23 +54,32 @@ def test_peer_store_child_group_command_and_its_clean_environment(monkeypatch):
     assert cmd[i + 1:] == ["--peer-child", "--gpus", "8", "--steps", "10", "--warmup", "2"]
     seen = {}
 
-    class Done:
-        returncode, stderr = 0, ""
-        stdout = 'noise\n{"peer_allgather": {"ranks": 8, "peer_store": {"value": 1.0}}}\n'
+    class FakeProc:
+        pid, returncode, hang = 4242, 0, False
+        stdout_text = 'noise\n{"peer_allgather": {"ranks": 8, "peer_store": {"value": 1.0}}}\n'
 
-    def fake_run(cmd, env, **kw):
-        seen.update(env=env, kw=kw)
-        return Done()
+        def __init__(self, cmd, env, **kw):
+            seen.update(env=env, kw=kw)
+
+        def communicate(self, timeout=None):
+            if FakeProc.hang and timeout is not None:
+                raise sp.TimeoutExpired("x", timeout)
+            return FakeProc.stdout_text, ""
     import subprocess as sp
-    monkeypatch.setattr(sp, "run", fake_run)
+    monkeypatch.setattr(sp, "Popen", FakeProc)
+    killed = []
+    monkeypatch.setattr(os, "killpg", lambda pgid, sig: killed.append(pgid))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
         monkeypatch.setenv(k, "7")
     assert bench.peer_store_child(8, 20, 5) == {"ranks": 8, "peer_store": {"value": 1.0}}
     assert not any(k in seen["env"] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID"))
     assert seen["env"]["FP8MI_BENCH_CHILD"] == "1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
-    assert seen["kw"]["timeout"] <= 480      # shorter than the 10 minutes the other ranks' rendezvous waits for rank 0
-    Done.stdout = "no line here\n"
-    assert "error" in bench.peer_store_child(8, 20, 5)
+    assert seen["kw"]["start_new_session"] is True     # a process group of its own: a timeout kills exactly that group
+    assert bench.PEER_CHILD_TIMEOUT_S <= 480            # shorter than the 10 minutes the other ranks' rendezvous waits for rank 0
+    FakeProc.stdout_text = "no line here\n"
+    assert "error" in bench.peer_store_child(8, 20, 5) and not killed
+    FakeProc.hang = True
+    assert "killed" in bench.peer_store_child(8, 20, 5)["error"] and killed == [4242]
 
 
 def test_nccl_debug_log_summary():
