@@ -811,8 +811,8 @@ def callsite_eager(dev, info):
     return out
 
 
-def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info, nbuf=None, sharded=False, n_streams=1, ceilings=None):
-    w = Workload(name, dev, world, rank, kernel, nbuf, sharded)
+def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info, nbuf=None, sharded=False, n_streams=1, ceilings=None, gather="rccl"):
+    w = Workload(name, dev, world, rank, kernel, nbuf, sharded, gather=gather)
     dt, graphed = time_steps(w, steps, warmup, True, world, n_streams)
     launches = steps * w.inner
     if w.unit_flops:
@@ -840,7 +840,14 @@ def measure(name, dev, steps, warmup, world, rank, kernel, with_cpu, info, nbuf=
                 fl["frac_at_dma_only"] = round(res["roofline"]["frac"] * res["roofline"]["kernel_avg_us"] / fl["dma_only_us"], 4)   # the roofline fraction this design would read if the kernel ran in dma_only_us
             res["roofline"]["floor"] = fl
     if w.sharded and dist.is_initialized():
-        res["allgather_only"] = allgather_only(w)   # GEMM-only rate is roofline.achieved, this is the collective
+        # GEMM-only rate is roofline.achieved, this is the gather alone - the form the step used
+        try:
+            res["allgather_only"] = dict(peer_gather_only(w), form="peer-store (include/fp8mi_peer.h)") if w.peer is not None else allgather_only(w)
+        except Exception as e:
+            res["allgather_only"] = {"error": repr(e)}
+    if w.peer is not None:
+        res["peer_timeout_status"] = w.peer.status()
+        w.peer.close()
     if with_cpu:
         res["cpu_baseline"] = cpu_baseline(w)
     del w
@@ -996,6 +1003,23 @@ def peer_store_child(n, steps, warmup, dry=False):
         return {"error": f"the child group printed no line (rc {proc.returncode}): {stderr[-400:]}"}
     except Exception as e:
         return {"error": repr(e)}
+
+
+def choose_gather(report, margin=1.05):
+    """-> (use the peer-store gather for the headline step?, why).  Only on evidence from this very node: both forms measured by the child group,
+    the peer-store step at least `margin` x the collective's throughput, the same bits on every rank, no bounded wait missed."""
+    c, p = report.get("collective") or {}, report.get("peer_store") or {}
+    if "value" not in c or "value" not in p:
+        return False, "the child group did not measure both forms: " + str(report.get("error") or c.get("error") or p.get("error") or "no values")
+    if not p.get("bit_equal_to_collective_on_every_rank"):
+        return False, "the peer-store result differed from the collective's on some rank"
+    if p.get("timeout_status", 1) != 0:
+        return False, f"a bounded wait of the peer-store gather timed out (status {p.get('timeout_status')})"
+    if report.get("backend") != "rccl":
+        return False, f"rehearsal backend {report.get('backend')}: not a measurement"
+    if p["value"] < margin * c["value"]:
+        return False, f"peer-store {p['value']} vs collective {c['value']} {c.get('unit', '')}: not faster by {margin}x"
+    return True, f"peer-store {p['value']} vs collective {c['value']} {c.get('unit', '')} in the child group on this node, bit-equal, no timeouts"
 
 
 def peer_gather_only(w, reps=10):
@@ -1162,9 +1186,22 @@ def main():
         print(json.dumps({"callsite_eager": callsite_eager(dev, info)}), flush=True)
         return
     ceilings = measure_ceilings(dev, info) if (world == 1 and not args.force_sharded and not args.no_ceilings) else None
+    # Which gather the headline step uses at N > 1: RCCL's collective unless the separate group of ranks (peer_store_child) has just measured the
+    # peer-store gather on THIS node as clearly faster, bit-equal on every rank and with every bounded wait met.  Rank 0 knows; the others are told.
+    gather, gather_why = "rccl", None
+    if world > 1:
+        choice = torch.zeros(1, dtype=torch.int32, device=dev)
+        if rank == 0 and peer_store is not None:
+            use, gather_why = choose_gather(peer_store)
+            choice[0] = 1 if use else 0
+        dist.broadcast(choice, src=0)
+        gather = "peer" if int(choice.item()) == 1 else "rccl"
+        forced = os.environ.get("FP8MI_BENCH_GATHER")   # "peer" / "rccl": rehearsals and A/B runs (the same on every rank: it is the environment)
+        if forced in ("peer", "rccl"):
+            gather, gather_why = forced, "forced by FP8MI_BENCH_GATHER"
     res = measure(primary, dev, args.steps, args.warmup, world, rank, args.kernel,
                   with_cpu=(world == 1 and rank == 0 and not args.no_cpu_baseline and not args.force_sharded and primary != "linear"),
-                  info=info, nbuf=args.nbuf, sharded=args.force_sharded, n_streams=args.streams, ceilings=ceilings)
+                  info=info, nbuf=args.nbuf, sharded=args.force_sharded, n_streams=args.streams, ceilings=ceilings, gather=gather)
     same_workload_1gpu = None
     if world > 1:
         # the N = 1 bench line is C3 (BASELINE.json's single-GPU config); for a like-for-like strong-scaling
@@ -1189,8 +1226,8 @@ def main():
                  "uniform": "synthetic (seeded uniform e4m3 bytes, NaN patterns remapped; weights rotate through > 256 MiB)",
                  "zeros": "synthetic (all-zero bytes; clock upper bound, not a reportable number)"}[args.data],
         "config": dict(res["config"], launches_per_step=res["launches_per_step"], hip_graph=res["hip_graph"],
-                       parallelism=("N-column-sharded x%d, 2 chunk-cyclic row chunks per rank, RCCL all-gather "
-                                    "pipelined under the GEMM (fp8_sharded_linear.py)" % world) if world > 1 else "single GPU",
+                       parallelism=("N-column-sharded x%d, 2 chunk-cyclic row chunks per rank, %s "
+                                    "pipelined under the GEMM (fp8_sharded_linear.py)" % (world, "peer-store all-gather (include/fp8mi_peer.h)" if gather == "peer" else "RCCL all-gather")) if world > 1 else "single GPU",
                        device=info["name"], arch=info["arch"], compute_units=info["compute_units"],
                        dev_kernarg=os.environ.get("HIP_FORCE_DEV_KERNARG", "0") == "1"),
         "roofline": res["roofline"],
@@ -1204,7 +1241,9 @@ def main():
     if same_workload_1gpu is not None:
         line["same_workload_on_one_gpu"] = same_workload_1gpu
     if peer_store is not None:
-        line["peer_allgather"] = peer_store
+        line["peer_allgather"] = dict(peer_store, headline_gather=gather, headline_gather_reason=gather_why)
+    if "peer_timeout_status" in res:
+        line["peer_timeout_status"] = res["peer_timeout_status"]
     if "cpu_baseline" in res:
         line["cpu_baseline"] = res["cpu_baseline"]
     if ceilings is not None:

@@ -82,6 +82,26 @@ def test_peer_store_child_group_command_and_its_clean_environment(monkeypatch):
     assert "killed" in bench.peer_store_child(8, 20, 5)["error"] and killed == [4242]
 
 
+def test_headline_gather_is_chosen_on_evidence_only():
+    sys.path.insert(0, ROOT)
+    import bench
+    good = {"backend": "rccl", "collective": {"value": 900.0, "unit": "TFLOP/s"},
+            "peer_store": {"value": 2400.0, "bit_equal_to_collective_on_every_rank": True, "timeout_status": 0}}
+    use, why = bench.choose_gather(good)
+    assert use and "2400.0" in why
+    for breakit in (lambda d: d["peer_store"].update(value=930.0),                                    # not clearly faster
+                    lambda d: d["peer_store"].update(bit_equal_to_collective_on_every_rank=False),
+                    lambda d: d["peer_store"].update(timeout_status=2),
+                    lambda d: d.update(backend="gloo"),                                               # a rehearsal is not a measurement
+                    lambda d: d.update(peer_store={"error": "boom"}),
+                    lambda d: d.pop("collective")):
+        d = json.loads(json.dumps(good))
+        breakit(d)
+        use, why = bench.choose_gather(d)
+        assert not use and why
+    assert bench.choose_gather({"error": "the child group printed no line"})[0] is False
+
+
 def test_nccl_debug_log_summary():
     import bench
     log = "\n".join([

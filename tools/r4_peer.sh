@@ -15,3 +15,14 @@ for ln in open("gpurun_out/r4p/line.json"):
         print("peer_allgather", json.dumps(d.get("peer_allgather"))[:3000])
 PY
 tail -5 $O/line.err
+# the headline step itself on the peer-store gather (on a real node bench.py chooses it when the child group measured it faster; here it is forced)
+FP8MI_BENCH_GATHER=peer timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29615 bench.py --gpus 2 --steps 3 --warmup 1 --no-peer-store > $O/line_peer.json 2> $O/line_peer.err
+echo "line (peer headline) rc=$?"; python - <<'PY'
+import json
+for ln in open("gpurun_out/r4p/line_peer.json"):
+    if ln.startswith('{"metric"'):
+        d = json.loads(ln)
+        print("value", d["value"], d["unit"], "n_gpus", d["n_gpus"], "ms_per_step", d["ms_per_step"], "hip_graph", d["config"]["hip_graph"])
+        print(d["config"]["parallelism"]); print("allgather_only", d.get("allgather_only"), "status", d.get("peer_timeout_status"))
+PY
+tail -3 $O/line_peer.err
