@@ -156,7 +156,7 @@ class Workload:
                 self.chunks = 2   # per-call RCCL latency vs overlap: 2 row chunks per rank
                 if gather == "peer":   # ONE IPC-mapped gather buffer for every weight buffer's linear (include/fp8mi_peer.h)
                     import fp8_peer_gather
-                    self.peer = fp8_peer_gather.PeerGather(N * M * esz, dev)
+                    self.peer = fp8_peer_gather.PeerGather(N * M * esz, dev, timeout_us=5_000_000)   # (a wait is microseconds; 5 s bounds a run that went wrong)
                 self.linears = [ColumnShardedFP8Linear(B, self.sb, None, N=N, chunks=self.chunks, out_dtype=self.out_dtype, peer=self.peer)
                                 for B in self.Bs]
                 self.Cs = [torch.empty(Nl, M, dtype=self.out_dtype, device=dev) for _ in range(2)]
@@ -1022,6 +1022,31 @@ def choose_gather(report, margin=1.05):
     return True, f"peer-store {p['value']} vs collective {c['value']} {c.get('unit', '')} in the child group on this node, bit-equal, no timeouts"
 
 
+def peer_canary(dev, world, rank):
+    """Before the headline step is put on the peer-store gather IN THIS group of ranks: three small gathers with short bounded waits, the data
+    checked, the status word read; the ranks agree (MIN).  False sends every rank back to the collective."""
+    ok = True
+    try:
+        import fp8_peer_gather
+        slab = 4096
+        pg = fp8_peer_gather.PeerGather(world * slab, dev, timeout_us=2_000_000)
+        buf = pg.tensor(torch.uint8)
+        for it in range(3):
+            buf[rank * slab:(rank + 1) * slab] = (rank * 17 + it * 5 + 1) % 251
+            pg.allgather(rank * slab, slab)
+            got = buf.view(world, slab)[:, ::512].clone()
+            want = torch.tensor([[(r * 17 + it * 5 + 1) % 251] for r in range(world)], dtype=torch.uint8, device=dev).expand(world, got.shape[1])
+            ok = ok and bool(torch.equal(got, want))
+        ok = ok and pg.status() == 0
+        pg.close()
+    except Exception as e:
+        log(f"[bench] peer-store canary failed on rank {rank}: {e!r}")
+        ok = False
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item()) == 1
+
+
 def peer_gather_only(w, reps=10):
     """The peer-store gather alone, slabs of the sharded linear's chunk size (the counterpart of allgather_only)."""
     dev, world = w.dev, w.world
@@ -1199,6 +1224,8 @@ def main():
         forced = os.environ.get("FP8MI_BENCH_GATHER")   # "peer" / "rccl": rehearsals and A/B runs (the same on every rank: it is the environment)
         if forced in ("peer", "rccl"):
             gather, gather_why = forced, "forced by FP8MI_BENCH_GATHER"
+        if gather == "peer" and not peer_canary(dev, world, rank):
+            gather, gather_why = "rccl", (gather_why or "") + "; but the canary gathers of THIS group of ranks failed: back to the collective"
     res = measure(primary, dev, args.steps, args.warmup, world, rank, args.kernel,
                   with_cpu=(world == 1 and rank == 0 and not args.no_cpu_baseline and not args.force_sharded and primary != "linear"),
                   info=info, nbuf=args.nbuf, sharded=args.force_sharded, n_streams=args.streams, ceilings=ceilings, gather=gather)
