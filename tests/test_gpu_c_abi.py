@@ -22,3 +22,16 @@ def test_c_abi_roundtrip_without_torch(cuda, tmp_path):
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "C ABI round trip: ok" in out.stdout
+
+
+def test_peer_allgather_c_abi_without_torch(cuda, tmp_path):
+    """include/fp8mi_peer.h from a plain C host (tests/c/peer_roundtrip.c): three forked ranks, handles exchanged through shared memory, 12 back-to-back
+    gathers checked on the host, argument errors, the bounded wait - no Python, no torch.distributed in those processes."""
+    exe = str(tmp_path / "peer_roundtrip")
+    cmd = ["gcc", "-O2", "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "tests", "c", "peer_roundtrip.c"), "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+           "-L" + PKG, "-lfp8mi_peer", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    subprocess.check_call(cmd)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=180, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "peer all-gather C round trip: ok" in out.stdout
