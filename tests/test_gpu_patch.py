@@ -1,6 +1,7 @@
 """GPU (MI355X): the monkey-patch surface end to end, restating the reference's
 integration tests (test_fp8_metal.py:318-705, test_mps_vs_cpu.py:283-357,
 validate_fix.py:50-160) with "cuda" (PyTorch-ROCm) in the role of "mps"."""
+import datetime
 import json
 import os
 
@@ -300,6 +301,17 @@ def test_transposed_epilogue_equals_untransposed_bits(native, cuda, oracle):
         assert np.all(np.abs(got.cpu().numpy().T - exact) <= 1e-3 * bound + 1e-30), (Mx, K, N, kern)
 
 
+def _reap(procs):
+    """No worker of a multi-process test outlives it (exactly the processes started here): a rank left waiting for a dead peer would keep the GPU busy under
+    whatever runs next."""
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+            p.join(timeout=20)
+            if p.is_alive():
+                p.kill()
+
+
 def _two_rank_worker(rank, world, port, q):
     """One of two processes sharing the ONE GPU of the box: real HIP kernels for the local product, a gloo group for the gather (RCCL refuses two
     ranks on one device; what is under test is the module's GPU branch - side stream, events, in-place slots - with a peer that really exists)."""
@@ -309,7 +321,7 @@ def _two_rank_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     try:
         import fp8_mi355x_native as native
         from fp8_sharded_linear import ColumnShardedFP8Linear
@@ -350,10 +362,13 @@ def test_sharded_linear_two_ranks_on_one_gpu(cuda):
     procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=240) for _ in range(2))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        res = sorted(q.get(timeout=240) for _ in range(2))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        _reap(procs)
     assert res == [(0, True), (1, True)]
 
 
@@ -366,7 +381,7 @@ def _peer_gather_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))   # a rank that died must not leave the others waiting for half an hour
     ok, note = True, ""
     try:
         import fp8_mi355x_native as native
@@ -463,8 +478,11 @@ def test_peer_allgather_three_ranks_on_one_gpu(cuda):
     procs = [ctx.Process(target=_peer_gather_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=300) for _ in range(world))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        res = sorted(q.get(timeout=300) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        _reap(procs)
     assert res == [(r, True, "") for r in range(world)], res
