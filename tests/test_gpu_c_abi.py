@@ -1,6 +1,7 @@
 """GPU: the C ABI used from a plain C program - no Python, no torch in the
 process - checked against the C oracle (tests/c/abi_roundtrip.c)."""
 import os
+import signal
 import subprocess
 
 import pytest
@@ -31,7 +32,15 @@ def test_peer_allgather_c_abi_without_torch(cuda, tmp_path):
     cmd = ["gcc", "-O2", "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "tests", "c", "peer_roundtrip.c"), "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
            "-L" + PKG, "-lfp8mi_peer", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
     subprocess.check_call(cmd)
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=180, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
-    print(out.stdout, out.stderr)
-    assert out.returncode == 0, out.stdout + out.stderr
-    assert "peer all-gather C round trip: ok" in out.stdout
+    # its own session: on a timeout the program AND the ranks it forked are killed (exactly the process group started here)
+    proc = subprocess.Popen([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True,
+                            env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    try:
+        stdout, stderr = proc.communicate(timeout=180)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        proc.communicate()
+        raise
+    print(stdout, stderr)
+    assert proc.returncode == 0, stdout + stderr
+    assert "peer all-gather C round trip: ok" in stdout
