@@ -68,6 +68,10 @@ struct Cfg {
     // (the launch itself with this kernel's grid, block and LDS allocation).  What each leaves out is hidden under the others in the real
     // kernel, so the floors bound the kernel from below; they do not add up to it.
     static constexpr int FLOOR = (ABL_ >> 4) & 3;
+    // Timing-only, diagnostic library (ids 137, 138): the B operand's stage loads go into a register sink as plain `buffer_load_dwordx4` instead of
+    // through the LDS-DMA (the B half of the ring stays zero: wrong results).  An upper bound on what a register-staged W loader could gain on the
+    // weight-streaming shapes, where plain loads were probed 10-15 % faster than the DMA path (profiles/r04_wstream_probe.txt).
+    static constexpr bool BREG = ((ABL_ >> 6) & 1) != 0;
     static constexpr int MODE = MODE_;  // 0: stage DMA issued first, then fragment reads + MFMAs; 1: fragment reads first (see run_tile)
     static constexpr int NSTAGE = NSTAGE_;
     static constexpr int PF = NSTAGE_ - 1;  // K-steps of loads in flight
@@ -166,6 +170,7 @@ struct StagePlan {
     uint32_t pf_off;    // C::PFD: this lane's line of the B panel's share to prefetch (kOOB: none)
     u32x4 pf_rsrc;      // ... and the B panel's descriptor as plain words (an asm operand)
     int pf_waves;       // how many waves prefetch (1 when the panel has 4 readers on the XCD, 2 with 2, 0 when this tile is its only reader)
+    mutable u32x4 bsink;  // C::BREG (timing-only): landing registers of the B operand's plain loads (never read)
 };
 
 template <typename C, bool TAIL>
@@ -186,6 +191,7 @@ FP8MI_DEVICE void issue_stage(const StagePlan<C> &pl, __amdgpu_buffer_rsrc_t ra,
         // the LDS image is consecutive 1-KiB groups (8 rows x 128 B), per K-step A's rows first, then B's
         lds_void *dst = (lds_void *)(stage + gs * 1024);
         if (is_a) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, (int)vo, k0, 0, 0);
+        else if constexpr (C::BREG) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(pl.bsink) : "v"(vo), "s"(pl.pf_rsrc), "s"((uint32_t)k0) : "memory");
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, (int)vo, k0, 0, 0);
     }
 }
@@ -479,6 +485,16 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThr
         pl.full = rows_a == BM && rows_b == BN;
         pl.pf_off = kOOB;
         pl.pf_waves = 0;
+        pl.bsink = u32x4{0u, 0u, 0u, 0u};
+        if constexpr (C::BREG) {   // (timing-only) the B panel's descriptor as plain words for the asm loads; the ring starts out zero: no NaN redo on stale LDS bytes
+            static_assert(C::PFD == 0, "BREG borrows the prefetch descriptor");
+            const uint64_t pbr = (uint64_t)(p.B + n0 * p.ldb);
+            pl.pf_rsrc = u32x4{(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pbr),
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(pbr >> 32) & 0xFFFFu)),
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)min(bytes_b, (int64_t)0x7FFFFFFF)), 0x00020000u};
+            for (int o = (int)threadIdx.x * 16; o < C::kRingBytes; o += C::kThreads * 16) *(u32x4 *)(smem + o) = u32x4{0u, 0u, 0u, 0u};
+            __syncthreads();
+        }
         if (C::PFD > 0) {
             // this tile's quarter of its B panel's lines for one stage (B has 4 readers on the XCD: the m-tiles of its group)
             constexpr int kLines = BN * C::KS / 4;
@@ -687,6 +703,8 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     case 153: return launch<32, 128, 16, 32, 3, 1, 0, 2, 4>(p, s);             // 32x128, 8 waves of 16x32, 3 x 40 KiB (M <= 32)
     case 154: return launch<32, 64, 16, 32, 4, 1, 0, 2, 4>(p, s);              // 32x64, 4 waves, 4 x 24 KiB
     case 155: return launch<16, 128, 16, 32, 4, 1, 0, 2, 2>(p, s);             // 16x128, 4 waves (2 loading), 4 x 36 KiB (M <= 16)
+    case 137: return launch<64, 64, 16, 32, 4, 1, 64, 2, 4>(p, s);             // 64x64 as shipped, B operand through plain loads into a register sink: TIMING ONLY (wrong results)
+    case 138: return launch<32, 64, 16, 32, 4, 1, 64, 2, 4>(p, s);             //   ... 32x64
     case 156: return launch<64, 64, 16, 32, 3, 1, 0, 2, 4>(p, s);              // 64x64, 8 waves, 3 x 32 KiB
     case 157: return launch<64, 64, 16, 32, 2, 1, 0, 2, 4>(p, s);              // 64x64, 8 waves, 2 x 32 KiB (two workgroups per CU)
     case 126: return launch<64, 16, 16, 16, 4, 1, 0, 2, 2>(p, s);              // 64x16, 4 waves (2 loading), 4 x 20 KiB: N / 16 tiles fill the chip at N = 4096 with NO K split (fp32 out only: timing experiment)
