@@ -705,6 +705,9 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     case 155: return launch<16, 128, 16, 32, 4, 1, 0, 2, 2>(p, s);             // 16x128, 4 waves (2 loading), 4 x 36 KiB (M <= 16)
     case 137: return launch<64, 64, 16, 32, 4, 1, 64, 2, 4>(p, s);             // 64x64 as shipped, B operand through plain loads into a register sink: TIMING ONLY (wrong results)
     case 138: return launch<32, 64, 16, 32, 4, 1, 64, 2, 4>(p, s);             //   ... 32x64
+    case 139: return launch<64, 64, 16, 32, 4, 1, 16, 2, 4>(p, s);             // 64x64 as shipped, timing-only floors (Cfg::FLOOR, with the split-K exchange the launch resolves): the DMA stream only
+    case 142: return launch<64, 64, 16, 32, 4, 1, 32, 2, 4>(p, s);             //   ... no K loop: launch + split-K exchange + epilogue
+    case 143: return launch<64, 64, 16, 32, 4, 1, 48, 2, 4>(p, s);             //   ... the launch alone
     case 156: return launch<64, 64, 16, 32, 3, 1, 0, 2, 4>(p, s);              // 64x64, 8 waves, 3 x 32 KiB
     case 157: return launch<64, 64, 16, 32, 2, 1, 0, 2, 4>(p, s);              // 64x64, 8 waves, 2 x 32 KiB (two workgroups per CU)
     case 126: return launch<64, 16, 16, 16, 4, 1, 0, 2, 2>(p, s);              // 64x16, 4 waves (2 loading), 4 x 20 KiB: N / 16 tiles fill the chip at N = 4096 with NO K split (fp32 out only: timing experiment)
