@@ -72,6 +72,10 @@ struct Cfg {
     // through the LDS-DMA (the B half of the ring stays zero: wrong results).  An upper bound on what a register-staged W loader could gain on the
     // weight-streaming shapes, where plain loads were probed 10-15 % faster than the DMA path (profiles/r04_wstream_probe.txt).
     static constexpr bool BREG = ((ABL_ >> 6) & 1) != 0;
+    // Timing experiment, diagnostic library (id 144): the K slices of a tile on ONE XCD (consecutive entries of the XCD's run of the work list) and the
+    // split-K exchange at GROUP scope - stores that stop at the XCD's L2, loads that start there, the arrival counter in it.  Right only as long as
+    // workgroup b really runs on XCD b mod 8, which the product never relies on for correctness (fp8mi_gemm_epi.h): it measures what that reliance would buy.
+    static constexpr bool XLOCAL = ((ABL_ >> 7) & 1) != 0;
     static constexpr int MODE = MODE_;  // 0: stage DMA issued first, then fragment reads + MFMAs; 1: fragment reads first (see run_tile)
     static constexpr int NSTAGE = NSTAGE_;
     static constexpr int PF = NSTAGE_ - 1;  // K-steps of loads in flight
@@ -453,6 +457,15 @@ __global__ __launch_bounds__((Cfg<BM, BN, WM, WN, NSTAGE, PP, ABL, KS, LD>::kThr
 #endif
     int tile_m, tile_n, kslice, wg;
     tile_of_block(blockIdx.x, nwg, tiles_m, tiles_n, tile_m, tile_n, kslice, wg);  // XCD-aware, grouped order (fp8mi_gemm_epi.h)
+    if constexpr (C::XLOCAL) {   // (timing experiment) slice fastest inside an XCD's run: a tile's slices sit on one XCD when the run is a multiple of the split
+        const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        const int wg_all = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ((int)blockIdx.x >> 3);
+        const int split = max(p.split, 1);
+        wg = wg_all / split;
+        kslice = wg_all - wg * split;
+        tile_m = wg % tiles_m;
+        tile_n = wg / tiles_m;
+    }
     const int n_tiles = tiles_m * tiles_n;
     const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
 
@@ -705,6 +718,7 @@ int fp8mi_launch_gemm(const MMParams &p, int variant, hipStream_t s)
     case 155: return launch<16, 128, 16, 32, 4, 1, 0, 2, 2>(p, s);             // 16x128, 4 waves (2 loading), 4 x 36 KiB (M <= 16)
     case 137: return launch<64, 64, 16, 32, 4, 1, 64, 2, 4>(p, s);             // 64x64 as shipped, B operand through plain loads into a register sink: TIMING ONLY (wrong results)
     case 138: return launch<32, 64, 16, 32, 4, 1, 64, 2, 4>(p, s);             //   ... 32x64
+    case 144: return launch<64, 64, 16, 32, 4, 1, 128, 2, 4>(p, s);            // 64x64 as shipped, a tile's K slices on one XCD and the exchange at group scope (Cfg::XLOCAL): what relying on the placement would buy
     case 139: return launch<64, 64, 16, 32, 4, 1, 16, 2, 4>(p, s);             // 64x64 as shipped, timing-only floors (Cfg::FLOOR, with the split-K exchange the launch resolves): the DMA stream only
     case 142: return launch<64, 64, 16, 32, 4, 1, 32, 2, 4>(p, s);             //   ... no K loop: launch + split-K exchange + epilogue
     case 143: return launch<64, 64, 16, 32, 4, 1, 48, 2, 4>(p, s);             //   ... the launch alone

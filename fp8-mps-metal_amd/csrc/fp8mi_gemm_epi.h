@@ -229,11 +229,15 @@ FP8MI_DEVICE void tile_of_block(int bid, int nwg, int tiles_m, int tiles_n, int 
 // Nobody waits.  Partials cross XCDs (private L2s), so they are written and read with sc0 sc1 (write-through /
 // miss-always) accesses - publishing them with __threadfence() (whole-L2 write-back + invalidate per wave) made the
 // same kernel 3-5x slower.  C::kCThreads threads (the waves that hold accumulators) call this, all of them.
+template <typename C, typename = void> struct xlocal_of { static constexpr bool value = false; };   // (configurations without the knob: the diagnostic producer / consumer kernel)
+template <typename C> struct xlocal_of<C, std::void_t<decltype(C::XLOCAL)>> { static constexpr bool value = C::XLOCAL; };
+
 template <typename C>
 FP8MI_DEVICE bool splitk_combine(const MMParams &p, f32x4 (&acc)[C::TN][C::TM], uint8_t *smem, int wg, int kslice, int nsplit,
                                  int n_tiles)
 {
-    constexpr int kCoherent = 17;  // aux bits: sc0 | sc1
+    constexpr bool kXLocal = xlocal_of<C>::value;
+    constexpr int kCoherent = kXLocal ? 1 : 17;  // aux bits: sc0 | sc1 (C::XLOCAL, diagnostic timing experiment: sc0 - the XCD's L2 is the meeting point)
     int *counters = (int *)p.ws;
     constexpr int kVecPerWg = C::TN * C::TM * C::kCThreads;  // f32x4 per partial tile (register order)
     __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
@@ -250,7 +254,8 @@ FP8MI_DEVICE bool splitk_combine(const MMParams &p, f32x4 (&acc)[C::TN][C::TM], 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's partial has reached memory ...
     volatile int *flag = (volatile int *)smem;
     __syncthreads();  // ... and so has every other thread's, before the workgroup's arrival is counted
-    if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(&counters[wg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) *flag = kXLocal ? __hip_atomic_fetch_add(&counters[wg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                            : __hip_atomic_fetch_add(&counters[wg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __syncthreads();
     const int arrived = *flag;
     if (arrived != nsplit - 1) return false;  // workgroup-uniform; nobody waits for anybody
@@ -280,7 +285,10 @@ FP8MI_DEVICE bool splitk_combine(const MMParams &p, f32x4 (&acc)[C::TN][C::TM], 
             }
         }
     }
-    if (threadIdx.x == 0) __hip_atomic_store(&counters[wg], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // zero for the next launch
+    if (threadIdx.x == 0) {  // zero for the next launch
+        if (kXLocal) __hip_atomic_store(&counters[wg], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_store(&counters[wg], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __syncthreads();  // the flag word is part of the ring the staged epilogue reuses
     return true;
 }
